@@ -1,0 +1,249 @@
+"""CPU oracle for the Whisper encoder-decoder greedy path.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module; the product (`whisper-trtllm_amd/`) never does and fails
+loudly when its HIP library is missing.
+
+This is a torch-CPU fp32, op-for-op restatement of the reference's bundled
+HuggingFace path (the oracle `BASELINE.json.north_star` names) plus the
+TensorRT-LLM engine-surface semantics layered on top of it.  Citations use
+  HF/ = /root/reference/transformers/src/transformers/
+  TL/ = /root/reference/tensorrt_llm_july-release-v1/
+
+Parity pinning: `tests/golden/*.npz` were produced by `tests/golden/make_golden.py`,
+which imports the bundled HF model in the build container, loads the same seeded
+weights and records its outputs; `tests/test_oracle.py` checks this file against
+those vectors (logits <= 1e-4, token ids exact).  The TensorRT engines themselves
+cannot be built here (closed TensorRT 9) — for that surface the oracle follows
+`TL/tensorrt_llm/models/whisper/model.py` as text: parity unpinned for the
+engine-only quirks (mask-shape cache gating at intermediate lengths).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Weights = Dict[str, torch.Tensor]
+
+
+def to_torch(weights: Dict[str, np.ndarray]) -> Weights:
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
+
+
+# ----------------------------------------------------------------------------- encoder
+def _encoder_attention(x: torch.Tensor, W: Weights, p: str, n_heads: int) -> torch.Tensor:
+    """HF/models/whisper/modeling_whisper.py:569-593 (WhisperEncoderAttention.forward)."""
+    B, T, D = x.shape
+    dh = D // n_heads
+    q = F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * (dh ** -0.5)  # :572 q scaled BEFORE QK^T
+    k = F.linear(x, W[p + "k_proj.weight"])                                       # k_proj has no bias (:547)
+    v = F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"])
+    sh = lambda t: t.view(B, T, n_heads, dh).transpose(1, 2)
+    q, k, v = sh(q), sh(k), sh(v)
+    att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)                           # :581-583, no mask is ever added
+    ctx = (att @ v).transpose(1, 2).reshape(B, T, D)
+    return F.linear(ctx, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
+
+
+def encoder_conv_frontend(W: Weights, cfg: dict, mel: torch.Tensor) -> torch.Tensor:
+    """HF modeling_whisper.py:992-997: conv1+GELU(erf), conv2(stride 2)+GELU, permute, + embed_positions."""
+    x = F.gelu(F.conv1d(mel, W["model.encoder.conv1.weight"], W["model.encoder.conv1.bias"], padding=1))
+    x = F.gelu(F.conv1d(x, W["model.encoder.conv2.weight"], W["model.encoder.conv2.bias"], stride=2, padding=1))
+    return x.permute(0, 2, 1) + W["model.encoder.embed_positions.weight"]
+
+
+def encoder_layer(W: Weights, cfg: dict, i: int, h: torch.Tensor) -> torch.Tensor:
+    """HF modeling_whisper.py:632-641 (pre-LN attention + pre-LN FFN)."""
+    p = f"model.encoder.layers.{i}."
+    D = cfg["d_model"]
+    r = h
+    x = F.layer_norm(h, (D,), W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"], 1e-5)
+    h = r + _encoder_attention(x, W, p + "self_attn.", cfg["encoder_attention_heads"])
+    r = h
+    x = F.layer_norm(h, (D,), W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"], 1e-5)
+    x = F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"]))
+    return r + F.linear(x, W[p + "fc2.weight"], W[p + "fc2.bias"])
+
+
+def encoder_forward(W: Weights, cfg: dict, mel: torch.Tensor) -> torch.Tensor:
+    """HF WhisperEncoder.forward modeling_whisper.py:992-1011 == TL model.py:90-111 (with erf GELU).
+
+    mel f32 [B, 80, 2*max_source_positions] -> f32 [B, max_source_positions, d_model]."""
+    h = encoder_conv_frontend(W, cfg, mel)
+    for i in range(cfg["encoder_layers"]):
+        h = encoder_layer(W, cfg, i, h)
+    D = cfg["d_model"]
+    return F.layer_norm(h, (D,), W["model.encoder.layer_norm.weight"], W["model.encoder.layer_norm.bias"], 1e-5)
+
+
+# ----------------------------------------------------------------------------- decoder (HF semantics)
+def _decoder_attention(x, W, p, n_heads, kv_states=None, past=None):
+    """HF modeling_whisper.py:468-526 (WhisperDecoderAttention.forward), four branches."""
+    B, T, D = x.shape
+    dh = D // n_heads
+    sh = lambda t: t.view(B, -1, n_heads, dh).transpose(1, 2)
+    q = F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * (dh ** -0.5)  # :472
+    if kv_states is not None and past is not None and past[0].shape[2] == kv_states.shape[1]:
+        k, v = past                                                               # :474-481 reuse cross K/V
+    elif kv_states is not None:                                                   # :484-486 first-step cross K/V
+        k = sh(F.linear(kv_states, W[p + "k_proj.weight"]))
+        v = sh(F.linear(kv_states, W[p + "v_proj.weight"], W[p + "v_proj.bias"]))
+    else:                                                                         # :490-503 self attention
+        k = sh(F.linear(x, W[p + "k_proj.weight"]))
+        v = sh(F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"]))
+        if past is not None:
+            k = torch.cat([past[0], k], dim=2)
+            v = torch.cat([past[1], v], dim=2)
+    att = torch.softmax(sh(q) @ k.transpose(-1, -2), dim=-1)                      # :513-515, no mask
+    ctx = (att @ v).transpose(1, 2).reshape(B, T, D)
+    return F.linear(ctx, W[p + "out_proj.weight"], W[p + "out_proj.bias"]), (k, v)
+
+
+def decoder_forward(W: Weights, cfg: dict, input_ids: torch.Tensor, enc_out: torch.Tensor, past=None):
+    """HF WhisperDecoder.forward :1143-1185 + proj_out :1433.
+
+    input_ids i64 [B, T] (T=1 on every greedy step), enc_out [B, S, D],
+    past: tuple over layers of (self_k, self_v, cross_k, cross_v) each [B,H,*,64] or None.
+    Returns (logits [B, T, V], present)."""
+    D = cfg["d_model"]
+    H = cfg["decoder_attention_heads"]
+    past_len = past[0][0].shape[2] if past is not None else 0                      # :1147
+    h = F.embedding(input_ids, W["model.decoder.embed_tokens.weight"])             # :1149 (embed_scale never applied)
+    h = h + W["model.decoder.embed_positions.weight"][past_len:past_len + input_ids.shape[1]]  # :1154, :308
+    present = []
+    for i in range(cfg["decoder_layers"]):
+        p = f"model.decoder.layers.{i}."
+        lp = past[i] if past is not None else None
+        r = h                                                                      # :710-751 WhisperDecoderLayer
+        x = F.layer_norm(h, (D,), W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"], 1e-5)
+        a, (sk, sv) = _decoder_attention(x, W, p + "self_attn.", H, None, lp[:2] if lp is not None else None)
+        h = r + a
+        r = h
+        x = F.layer_norm(h, (D,), W[p + "encoder_attn_layer_norm.weight"], W[p + "encoder_attn_layer_norm.bias"], 1e-5)
+        a, (ck, cv) = _decoder_attention(x, W, p + "encoder_attn.", H, enc_out, lp[2:] if lp is not None else None)
+        h = r + a
+        r = h
+        x = F.layer_norm(h, (D,), W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"], 1e-5)
+        x = F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"]))
+        h = r + F.linear(x, W[p + "fc2.weight"], W[p + "fc2.bias"])
+        present.append((sk, sv, ck, cv))
+    h = F.layer_norm(h, (D,), W["model.decoder.layer_norm.weight"], W["model.decoder.layer_norm.bias"], 1e-5)
+    logits = F.linear(h, W["proj_out.weight"])                                      # :1433, tied, no bias
+    return logits, tuple(present)
+
+
+# ----------------------------------------------------------------------------- decoder (engine surface)
+def engine_decoder_step(W: Weights, cfg: dict, data: torch.Tensor, enc_out: torch.Tensor,
+                        self_past_key: torch.Tensor, self_past_value: torch.Tensor,
+                        cross_past_key: torch.Tensor, cross_past_value: torch.Tensor,
+                        m_s: int, m_c: int):
+    """The TensorRT-LLM WhisperDecoder engine contract (TL model.py:407-470), batch 1.
+
+    data i32 [1,1]; caches [L,H,s,64] / [L,H,S_enc,64]; m_s/m_c = LENGTHS of the two mask inputs (values unused).
+      position row         = m_s - 1                               (model.py:424)
+      self  cache_len      = min(m_s - 1, s)                       (model.py:278)
+      cross cache_len  c   = m_c - 1 ; cur = proj(enc[0 : S-c])    (model.py:264-269, slice starts at 0)
+    Follows HF numerics (erf GELU, q pre-scaled) where the two differ.
+    Returns (logits [1,1,V], next_self_keys, next_self_values, next_cross_keys, next_cross_values)."""
+    D, H, L = cfg["d_model"], cfg["decoder_attention_heads"], cfg["decoder_layers"]
+    S = cfg["max_source_positions"]
+    dh = D // H
+    sh = lambda t: t.view(1, -1, H, dh).transpose(1, 2)
+    h = F.embedding(data.long(), W["model.decoder.embed_tokens.weight"])
+    h = h + W["model.decoder.embed_positions.weight"][m_s - 1:m_s - 1 + data.shape[1]]
+    nsk, nsv, nck, ncv = [], [], [], []
+
+    def attend(x, p, k, v):
+        q = sh(F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * (dh ** -0.5))
+        att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+        ctx = (att @ v).transpose(1, 2).reshape(1, -1, D)
+        return F.linear(ctx, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
+
+    for i in range(L):
+        p = f"model.decoder.layers.{i}."
+        r = h
+        x = F.layer_norm(h, (D,), W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"], 1e-5)
+        c = min(m_s - 1, self_past_key.shape[2])
+        k = torch.cat([self_past_key[i:i + 1, :, :c], sh(F.linear(x, W[p + "self_attn.k_proj.weight"]))], dim=2)
+        v = torch.cat([self_past_value[i:i + 1, :, :c],
+                       sh(F.linear(x, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]))], dim=2)
+        h = r + attend(x, p + "self_attn.", k, v)
+        nsk.append(k); nsv.append(v)
+        r = h
+        x = F.layer_norm(h, (D,), W[p + "encoder_attn_layer_norm.weight"], W[p + "encoder_attn_layer_norm.bias"], 1e-5)
+        c = m_c - 1
+        cur = enc_out[:, 0:S - c]
+        k = torch.cat([cross_past_key[i:i + 1, :, :c], sh(F.linear(cur, W[p + "encoder_attn.k_proj.weight"]))], dim=2)
+        v = torch.cat([cross_past_value[i:i + 1, :, :c],
+                       sh(F.linear(cur, W[p + "encoder_attn.v_proj.weight"], W[p + "encoder_attn.v_proj.bias"]))], dim=2)
+        h = r + attend(x, p + "encoder_attn.", k, v)
+        nck.append(k); ncv.append(v)
+        r = h
+        x = F.layer_norm(h, (D,), W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"], 1e-5)
+        x = F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"]))
+        h = r + F.linear(x, W[p + "fc2.weight"], W[p + "fc2.bias"])
+    h = F.layer_norm(h, (D,), W["model.decoder.layer_norm.weight"], W["model.decoder.layer_norm.bias"], 1e-5)
+    logits = F.linear(h, W["proj_out.weight"])
+    return logits, torch.cat(nsk, 0), torch.cat(nsv, 0), torch.cat(nck, 0), torch.cat(ncv, 0)
+
+
+# ----------------------------------------------------------------------------- generation
+def apply_logits_processors(cfg: dict, cur_len: int, prompt_len: int, scores: torch.Tensor) -> torch.Tensor:
+    """run.py:150-162 == HF generation/utils.py:890-902; classes HF generation/logits_process.py:1281-1328.
+
+    Order Suppress -> SuppressAtBegin -> Force; `cur_len` = input_ids.shape[1] at the call."""
+    scores = scores.clone()
+    scores[:, list(cfg["suppress_tokens"])] = -float("inf")                        # :1308-1310
+    begin_index = prompt_len if cfg.get("forced_bos_token_id") is None else prompt_len + 1
+    begin_index += cfg["forced_decoder_ids"][-1][0]                                # utils.py:897-899
+    if cur_len == begin_index:                                                     # :1293-1295
+        scores[:, list(cfg["begin_suppress_tokens"])] = -float("inf")
+    forced = dict(cfg["forced_decoder_ids"]).get(cur_len, None)                    # :1321-1327
+    if forced is not None:
+        scores[:, :] = -float("inf")
+        scores[:, forced] = 0
+    return scores
+
+
+def greedy_search(W: Weights, cfg: dict, enc_out: torch.Tensor, max_length: Optional[int] = None,
+                  return_logits: bool = False, force_eos_at: Optional[int] = None):
+    """run.py:171-227 == HF generation/utils.py:1474-1529 with the HF decoder as the model.
+
+    Starts from [[decoder_start_token_id]] per row (run.py:273); stops when every row has emitted EOS or
+    len >= max_length (MaxLengthCriteria, HF stopping_criteria.py:61-70).  `force_eos_at=n` (bench only)
+    makes step n emit EOS for every row, emulating a LibriSpeech-length transcript on random weights."""
+    B = enc_out.shape[0]
+    max_length = cfg["max_length"] if max_length is None else max_length
+    eos, pad = cfg["eos_token_id"], cfg["pad_token_id"]
+    ids = torch.full((B, 1), cfg["decoder_start_token_id"], dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+    past = None
+    all_logits: List[torch.Tensor] = []
+    step = 0
+    while True:
+        logits, past = decoder_forward(W, cfg, ids[:, -1:], enc_out, past)
+        nxt_logits = logits[:, -1, :]
+        if return_logits:
+            all_logits.append(nxt_logits.clone())
+        scores = apply_logits_processors(cfg, ids.shape[1], 1, nxt_logits)
+        nxt = torch.argmax(scores, dim=-1)
+        if force_eos_at is not None and step == force_eos_at:
+            nxt = torch.full_like(nxt, eos)
+        nxt = nxt * unfinished + pad * (1 - unfinished)                            # utils.py:1509
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        unfinished = unfinished * (nxt != eos).long()                              # utils.py:1514
+        step += 1
+        if unfinished.max() == 0 or ids.shape[1] >= max_length:
+            break
+    if return_logits:
+        return ids, torch.stack(all_logits, dim=1)
+    return ids
+
+
+def transcribe(W: Weights, cfg: dict, mel: torch.Tensor, **kw):
+    """Encoder + greedy decode == `hf_model.generate(mel)` in run.py:305-306."""
+    return greedy_search(W, cfg, encoder_forward(W, cfg, mel), **kw)

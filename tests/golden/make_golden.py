@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's bundled HuggingFace Whisper (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+It imports `/root/reference/transformers/src` (author-simplified transformers 4.33.0.dev0 — the
+oracle `BASELINE.json.north_star` names), loads this repo's seeded synthetic weights into
+`WhisperForConditionalGeneration` via `load_state_dict`, and records what the reference computes:
+encoder activations, per-step decoder logits, K/V rows and greedy token ids from `generate()`.
+Only DATA is written (tests/golden/<case>.npz); no reference source travels.  The GPU box and the
+CPU test-suite regenerate the identical weights/inputs from `synthetic.py` and compare against these.
+
+The one local stub: `transformers.dependency_versions_check` raises an ordinary ImportError on the
+installed `tokenizers` version, so a no-op module is pre-seeded for it.
+"""
+import contextlib
+import hashlib
+import json
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = "/root/reference/transformers/src"
+
+
+def import_reference_hf():
+    stub = types.ModuleType("transformers.dependency_versions_check")
+    stub.dep_version_check = lambda *a, **k: None
+    sys.modules["transformers.dependency_versions_check"] = stub
+    sys.path.insert(0, REF_SRC)
+    import transformers
+    assert transformers.__version__ == "4.33.0.dev0", transformers.__version__
+    assert transformers.__file__.startswith(REF_SRC), transformers.__file__
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from transformers.modeling_outputs import BaseModelOutput
+    return WhisperConfig, WhisperForConditionalGeneration, BaseModelOutput
+
+
+def build_hf(cfg, weights, WhisperConfig, Model):
+    keys = ["vocab_size", "num_mel_bins", "encoder_layers", "encoder_attention_heads", "decoder_layers",
+            "decoder_attention_heads", "decoder_ffn_dim", "encoder_ffn_dim", "decoder_start_token_id",
+            "activation_function", "d_model", "scale_embedding", "max_source_positions", "max_target_positions",
+            "pad_token_id", "bos_token_id", "eos_token_id", "suppress_tokens", "begin_suppress_tokens"]
+    hf_cfg = WhisperConfig(**{k: cfg[k] for k in keys}, forced_decoder_ids=cfg["forced_decoder_ids"],
+                           max_length=cfg["max_length"])
+    model = Model(hf_cfg).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("proj_out" in m for m in missing), missing
+    assert model.proj_out.weight.data_ptr() == model.model.decoder.embed_tokens.weight.data_ptr()  # tied
+    return model
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t, dtype=np.float32).tobytes()).hexdigest()
+
+
+def sub(t):
+    """Deterministic strided subsample of the trailing two dims, kept small."""
+    a = np.asarray(t)
+    return np.ascontiguousarray(a[..., ::max(1, a.shape[-2] // 24), ::max(1, a.shape[-1] // 32)])
+
+
+def main():
+    sys.path.insert(0, ROOT)
+    import whisper_trtllm_amd  # noqa: F401  (alias loader for the hyphenated package dir)
+    from whisper_trtllm_amd import synthetic
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_ref
+
+    WhisperConfig, Model, BaseModelOutput = import_reference_hf()
+    torch.manual_seed(0)
+    cases = [  # (case, config, weight seed, batch, config overrides)
+        ("toy-short_b3", "toy-short", 11, 3, {}),
+        # same model, EOS remapped onto tokens the greedy path emits: row 0 finishes early and is padded
+        # (pad != eos), then every row finishes at once and the loop stops before max_length
+        ("toy-short-eos1_b3", "toy-short", 11, 3, {"eos_token_id": 436, "pad_token_id": 77}),
+        ("toy-short-eosall_b3", "toy-short", 11, 3, {"eos_token_id": 76, "pad_token_id": 77}),
+        ("toy-wide_b2", "toy-wide", 12, 2, {}),
+        ("toy_b1", "toy", 13, 1, {}),
+        ("tiny_b2", "whisper-tiny.en", 14, 2, {"max_length": 24}),
+    ]
+    for case, cname, seed, B, overrides in cases:
+        cfg = synthetic.get_config(cname)
+        cfg.update(overrides)
+        weights = synthetic.make_weights(cfg, seed)
+        mel = synthetic.make_mel(cfg, index=7 * seed, batch=B)
+        model = build_hf(cfg, weights, WhisperConfig, Model)
+        out = {"config_name": cname, "seed": seed, "batch": B, "mel_index": 7 * seed,
+               "overrides_json": json.dumps(overrides)}
+        with torch.no_grad():
+            x = torch.from_numpy(mel)
+            enc = model.model.encoder
+            # encoder internals (HF modeling_whisper.py:992-1011)
+            c1 = torch.nn.functional.gelu(enc.conv1(x))
+            c2 = torch.nn.functional.gelu(enc.conv2(c1))
+            h0 = c2.permute(0, 2, 1) + enc.embed_positions.weight
+            h1 = enc.layers[0](h0, None, layer_head_mask=None)[0]
+            enc_out = enc(x).last_hidden_state
+            out.update(conv1=sub(c1), frontend=sub(h0), enc_layer0=sub(h1), enc_out=sub(enc_out),
+                       enc_out_sha=sha(enc_out), enc_out_absmax=float(enc_out.abs().max()))
+            # greedy ids through the reference's own generate() (run.py:305-306)
+            with contextlib.redirect_stdout(io.StringIO()):  # leftover print()s in generation/utils.py:911,919
+                ids = model.generate(x)
+            out["ids"] = ids.numpy().astype(np.int64)
+            # per-step logits with the HF cache protocol, teacher-forced on the generated ids
+            eo = BaseModelOutput(last_hidden_state=enc_out)
+            past = None
+            logits_steps, margins = [], []
+            k0_rows, v0_rows = [], []
+            for t in range(ids.shape[1] - 1):
+                o = model(encoder_outputs=eo, decoder_input_ids=ids[:, t:t + 1], past_key_values=past, use_cache=True)
+                past = o.past_key_values
+                lg = o.logits[:, -1, :]
+                logits_steps.append(lg.numpy().copy())
+                top2 = torch.topk(lg, 2, dim=-1).values
+                margins.append((top2[:, 0] - top2[:, 1]).numpy())
+                k0_rows.append(past[0][0][:, :, -1, :].numpy().copy())   # layer-0 self K row t  [B,H,64]
+                v0_rows.append(past[-1][1][:, :, -1, :].numpy().copy())  # last-layer self V row t
+            L = np.stack(logits_steps, 1)                                  # [B, steps, V]
+            out["logits_sub"] = np.ascontiguousarray(L[:, :, ::max(1, L.shape[-1] // 256)])
+            out["logits_stride"] = max(1, L.shape[-1] // 256)
+            out["logits_argmax"] = L.argmax(-1)
+            out["logits_max"] = L.max(-1)
+            out["logits_margin"] = np.stack(margins, 1)
+            out["self_k0_rows"] = np.stack(k0_rows, 1)                     # [B, steps, H, 64]
+            out["self_vL_rows"] = np.stack(v0_rows, 1)
+            out["cross_k0"] = sub(past[0][2].numpy())
+            out["cross_vL"] = sub(past[-1][3].numpy())
+
+            # cross-check this repo's oracle against the reference in-process
+            W = cpu_ref.to_torch(weights)
+            o_enc = cpu_ref.encoder_forward(W, cfg, x)
+            o_ids, o_logits = cpu_ref.greedy_search(W, cfg, o_enc, return_logits=True)
+            d_enc = float((o_enc - enc_out).abs().max())
+            d_log = float(np.abs(o_logits.numpy() - L).max())
+            same = bool(torch.equal(o_ids, ids))
+            print(f"[{case}] ids {tuple(ids.shape)} first row {ids[0, :10].tolist()} | oracle vs HF: "
+                  f"enc {d_enc:.2e} logits {d_log:.2e} ids_equal={same} | min top-2 margin "
+                  f"{out['logits_margin'].min():.3e}")
+            assert same and d_enc < 1e-4 and d_log < 1e-4
+        np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)
+        print("   wrote", case + ".npz", os.path.getsize(os.path.join(HERE, case + ".npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()
