@@ -1,0 +1,152 @@
+/*
+ * whisper_trtllm_amd.h — C-ABI of the MI355X-native Whisper encoder/decoder engine.
+ *
+ * This is the drop-in boundary for the hot path of EdVince/whisper-trtllm
+ * (tensorrt_llm/models/whisper/model.py + examples/whisper/run.py).  The reference crosses the
+ * process→device boundary through TensorRT's execution context, wrapped by
+ *   tensorrt_llm/runtime/session.py:54   Session.from_serialized_engine(bytes)
+ *   tensorrt_llm/runtime/session.py:116  Session.infer_shapes(List[TensorInfo]) -> List[TensorInfo] | None
+ *   tensorrt_llm/runtime/session.py:148  Session.run(inputs, outputs, stream) -> bool   (async enqueue)
+ * and its only native C symbol is `initLibNvInferPlugins` (cpp/tensorrt_llm/plugins/api/InferPlugin.cpp:151),
+ * loaded with ctypes.CDLL in tensorrt_llm/plugin/plugin.py:10-22.  TensorRT does not exist on ROCm, so the
+ * C-ABI below is shaped like Session: an opaque engine handle built from a serialized blob, shape inference
+ * by tensor name, and a stream-ordered run with name -> device-pointer bindings.  Entry points (5)-(9) add
+ * the batched in-place-KV fast path that replaces run.py's per-token Session.run + clone loop.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative WT_E_* code; nothing throws across the ABI;
+ *     `wt_last_error()` returns a thread-local human-readable message for the last failure.
+ *   - the caller owns every I/O buffer (device pointers, e.g. torch tensors); the engine owns weights,
+ *     workspace and the resident KV cache.  No torch types appear in any signature.
+ *   - calls are stream-ordered on the `hipStream_t` passed as `void* stream`; only wt_decoder_poll and
+ *     wt_decoder_greedy synchronise (documented below).  First use with a new batch size allocates workspace.
+ *   - one handle per device; a handle is NOT thread-safe (matches one IExecutionContext per Session,
+ *     session.py:48); distinct handles may be driven concurrently.
+ */
+#ifndef WHISPER_TRTLLM_AMD_H
+#define WHISPER_TRTLLM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WT_ABI_VERSION 1
+
+/* error codes */
+#define WT_OK 0
+#define WT_E_INVALID (-22)   /* bad argument / malformed blob / shape or dtype mismatch */
+#define WT_E_NOMEM (-12)     /* device or host allocation failed */
+#define WT_E_NOTFOUND (-2)   /* unknown tensor name */
+#define WT_E_HIP (-5)        /* a HIP runtime call failed; message carries hipGetErrorString */
+#define WT_E_UNSUPPORTED (-38)
+#define WT_E_STATE (-1)      /* call sequence violated (e.g. steps before begin) */
+
+/* tensor element types (numbering is ours; the Python shim maps trt.float32 etc. onto it) */
+typedef enum { WT_F32 = 0, WT_F16 = 1, WT_I32 = 2, WT_I8 = 3 } wt_dtype;
+typedef enum { WT_KIND_ENCODER = 1, WT_KIND_DECODER = 2 } wt_engine_kind;
+
+#define WT_MAX_DIMS 6
+#define WT_NAME_LEN 48
+
+/* == TensorInfo(name, dtype, shape) of session.py:28-33 */
+typedef struct {
+    char name[WT_NAME_LEN];
+    int32_t dtype; /* wt_dtype */
+    int32_t ndim;
+    int64_t shape[WT_MAX_DIMS];
+} wt_tensor_desc;
+
+/* one entry of the inputs/outputs dict of Session.run (session.py:166-176): name -> device pointer */
+typedef struct {
+    const char* name;
+    void* ptr;
+} wt_binding;
+
+typedef struct wt_engine wt_engine;
+
+/* model hyper-parameters baked into the blob (HF config keys, build_encoder.py:48-56 / build_decoder.py:45-56) */
+typedef struct {
+    int32_t kind;      /* wt_engine_kind */
+    int32_t precision; /* wt_dtype of the weights/compute: WT_F32 */
+    int32_t d_model, n_heads, n_layers, ffn_dim;
+    int32_t n_mels, max_source_positions, max_target_positions, vocab_size;
+} wt_engine_info;
+
+/* (1) replaces Session.from_serialized_engine (session.py:54): parse the blob, upload weights to `device`. */
+int wt_engine_open(const void* blob, size_t nbytes, int device, wt_engine** out);
+/* (2) engine teardown (TensorRT: ICudaEngine/IExecutionContext destructors). */
+void wt_engine_close(wt_engine* e);
+int wt_engine_get_info(const wt_engine* e, wt_engine_info* out);
+
+/* (3) replaces Session.infer_shapes (session.py:116-146): check names/dtypes of the inputs, remember the
+ * input shapes for the next run, and report the outputs.  `*n_out` is in: capacity of `out`, out: count.
+ * Encoder  in : data f32 [B,n_mels,2*S], length f32 [B] (ignored)            out: hidden_states f32 [B,S,d]
+ * Decoder  in : data i32 [1,1], length i32 [1] (ignored), encoder_hidden_states f32 [1,S,d],
+ *               self_past_key/value f32 [L,H,s,64], cross_past_key/value f32 [L,H,S,64],
+ *               past_self_cache_mask f32 [m_s], past_cross_cache_mask f32 [m_c]  (only the LENGTHS are read)
+ *          out: hidden_states f32 [1,1,V] (logits), next_self_keys/values f32 [L,H,min(m_s-1,s)+1,64],
+ *               next_cross_keys/values f32 [L,H,S,64]            (model.py:474-516, :459-468) */
+int wt_engine_infer_shapes(wt_engine* e, const wt_tensor_desc* in, int n_in, wt_tensor_desc* out, int* n_out);
+
+/* (4) replaces Session.run (session.py:148-178) == context.execute_async_v3(stream): enqueue one engine
+ * execution with the shapes of the last wt_engine_infer_shapes call.  Asynchronous: 0 != finished. */
+int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const wt_binding* out, int n_out, void* stream);
+
+/* (5) batched encoder: mel f32 [batch, n_mels, 2*S] -> hidden f32 [batch, S, d].  Asynchronous. */
+int wt_encoder_forward(wt_engine* enc, const float* mel, int batch, float* hidden_out, void* stream);
+
+/* greedy-search rules == get_logits_processor / get_stopping_criteria of run.py:150-169 */
+typedef struct {
+    int32_t decoder_start_token_id;
+    int32_t eos_token_id;
+    int32_t pad_token_id;
+    int32_t max_length;               /* MaxLengthCriteria: stop when len >= max_length */
+    int32_t begin_index;              /* SuppressTokensAtBeginLogitsProcessor.begin_index */
+    const int32_t* suppress_tokens;   /* host pointers, copied at begin */
+    int32_t n_suppress_tokens;
+    const int32_t* begin_suppress_tokens;
+    int32_t n_begin_suppress_tokens;
+    const int32_t* forced_decoder_ids; /* n_forced pairs (generation index, token id) */
+    int32_t n_forced;
+    int32_t force_eos_step;           /* bench only: emit EOS at this 0-based step for every row; -1 = off */
+    float* logits_trace;              /* optional device buffer f32 [batch, max_length-1, V] of raw logits, or NULL */
+} wt_greedy_params;
+
+/* (6) start a greedy decode of `batch` utterances: project the encoder memory f32 [batch,S,d] into the
+ * resident cross-KV cache, reset the self-KV cache and the id buffer to [[decoder_start_token_id]]*batch.
+ * Replaces greedy_search() step 0 (run.py:171-197 with past_key_values=None).  Asynchronous. */
+int wt_decoder_begin(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p, void* stream);
+/* (7) enqueue `n_steps` decoder steps (token embed -> L layers -> vocab projection -> logits processors ->
+ * argmax -> pad/EOS bookkeeping -> append), all on device.  Steps after every row finished are no-ops.
+ * Replaces the body of run.py:195-217.  Asynchronous. */
+int wt_decoder_steps(wt_engine* dec, int n_steps, void* stream);
+/* (8) synchronise `stream` and report progress: current sequence length (prompt included), number of
+ * unfinished rows, and whether the stop test of run.py:219-226 has fired. */
+int wt_decoder_poll(wt_engine* dec, int* cur_len, int* n_unfinished, int* done, void* stream);
+/* copy the generated ids (int32 [batch, cur_len], row-major) into a DEVICE buffer of capacity
+ * batch*max_length int32; stream-ordered. */
+int wt_decoder_read_ids(wt_engine* dec, int32_t* ids_out, int ld, void* stream);
+/* (9) convenience: begin + steps/poll until done; writes ids int32 [batch, max_length] (row stride
+ * max_length) to DEVICE memory and the final length to *out_len.  Synchronises the stream. */
+int wt_decoder_greedy(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p,
+                      int32_t* ids_out, int* out_len, void* stream);
+
+/* per-phase device timers (hipEvents on the caller's stream) for bench.py's roofline block */
+typedef struct {
+    float ms_total;    /* sum over launches of the timed kernel since the last reset */
+    int64_t launches;
+} wt_kernel_timer;
+/* enable/disable event timing of the dominant decode kernel (cross-attention) and the encoder GEMM */
+int wt_engine_set_profiling(wt_engine* e, int enabled);
+int wt_engine_get_timer(wt_engine* e, const char* which, wt_kernel_timer* out);
+
+const char* wt_last_error(void);
+int wt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,33 @@
+/*
+ * whisper_trtllm_amd_debug.h — kernel-level test hooks of libwhisper_trtllm_amd.so.
+ *
+ * NOT part of the drop-in boundary (that is whisper_trtllm_amd.h).  These launch one HIP kernel each on
+ * caller-provided device buffers so tests/test_gpu_kernels.py can check every kernel against a plain
+ * fp32 torch reference at edge shapes (ragged tiles, K tails, every batch-width instantiation).
+ * All pointers are device pointers; calls are asynchronous on `stream`; 0 = ok, else see wt_last_error().
+ */
+#ifndef WHISPER_TRTLLM_AMD_DEBUG_H
+#define WHISPER_TRTLLM_AMD_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[M][N] = act(A[M][K(lda)] W[N][K]^T + bias) (+ resid); act: 0 none, 1 erf-GELU */
+int wt_dbg_gemm(const float* A, int lda, const float* W, const float* bias, const float* resid, float* C, int M, int N,
+                int K, int act, void* stream);
+int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream);
+/* qkv [B*S][3*H*64] -> ctx [B*S][H*64], softmax(QK^T/8)V per head */
+int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, void* stream);
+/* Y[B][N] = act((X' W^T + bias) * scale) (+ resid); xmode 0: X'=X[B][K], 1: X'=LayerNorm(X), 2: X = decode-attention
+ * partials [B][K/64][n_split][68] merged on the fly */
+int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const float* W, const float* bias,
+                  const float* resid, float* Y, int B, int N, int K, int xmode, int n_split, int act, float scale,
+                  void* stream);
+/* q [B][H*64], k/v cache [B][H][s_cap][64], first `len` rows valid -> partials [B][H][n_split][68] */
+int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int B, int H,
+                            int s_cap, int len, int n_split, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

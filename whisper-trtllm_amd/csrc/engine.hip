@@ -1,0 +1,812 @@
+// C-ABI of the MI355X Whisper engine (include/whisper_trtllm_amd.h): blob parsing, weight upload, workspace,
+// encoder forward, the Session-compatible by-value decoder step, and the resident-KV greedy fast path with
+// hipGraph replay.  Reference call sites replaced: tensorrt_llm/runtime/session.py:54-178 (Session) and
+// examples/whisper/run.py:57-227 (engine wrappers + greedy_search).
+#include "../../include/whisper_trtllm_amd.h"
+#include "wt_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace wt;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return fail(WT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                            \
+    } while (0)
+
+struct DevTensor {
+    float* ptr = nullptr;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+};
+
+struct EncLayerW {
+    const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+struct DecLayerW {
+    const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b;
+    const float *ln2_w, *ln2_b, *cq_w, *cq_b, *ckv_w, *ckv_b, *co_w, *co_b;
+    const float *ln3_w, *ln3_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+
+struct EvTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double ms = 0.0;
+    long long launches = 0;
+};
+
+struct wt_engine {
+    int kind = 0, device = 0, precision = WT_F32;
+    int d = 0, H = 0, L = 0, F = 0, C = 0, S = 0, T = 0, V = 0;
+    char* weights_base = nullptr;
+    std::map<std::string, DevTensor> w;
+    // encoder
+    std::vector<EncLayerW> enc_layers;
+    const float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr, *enc_pos = nullptr,
+                *enc_ln_w = nullptr, *enc_ln_b = nullptr;
+    int enc_cap = 0;
+    char* enc_ws = nullptr;
+    float *melT = nullptr, *c1 = nullptr, *hbuf = nullptr, *xbuf = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
+    // decoder
+    std::vector<DecLayerW> dec_layers;
+    const float *tok_emb = nullptr, *pos_emb = nullptr, *proj_w = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+    int dec_cap = 0, dec_maxlen_cap = 0;
+    char* dec_ws = nullptr;
+    float *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
+    float *dh = nullptr, *dq = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
+    DecState* st = nullptr;
+    int *ids = nullptr, *unfinished = nullptr, *forced = nullptr;
+    uint8_t* mask = nullptr;
+    DecState* h_state = nullptr;  // pinned
+    // greedy session
+    bool begun = false;
+    int B = 0, max_length = 0, begin_index = 0, eos = 0, pad = 0, force_eos_step = -1, nsplit_self = 1, nsplit_cross = 4;
+    float* trace = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_valid = false, use_graph = true;
+    // Session-compat shapes (set by infer_shapes)
+    bool shapes_ok = false;
+    int c_B = 1, c_s = 0, c_ms = 0, c_mc = 0;
+    // profiling
+    bool profiling = false;
+    EvTimer t_cross, t_gemm, t_enc_attn, t_skinny;
+};
+
+// ------------------------------------------------------------------------------------------------- helpers
+static void timer_begin(wt_engine* e, EvTimer& t, hipStream_t s, hipEvent_t* a, hipEvent_t* b) {
+    *a = *b = nullptr;
+    if (!e->profiling) return;
+    if (t.pool.empty()) {
+        hipEvent_t x, y;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return;
+        t.pool.push_back({x, y});
+    }
+    auto pr = t.pool.back();
+    t.pool.pop_back();
+    *a = pr.first;
+    *b = pr.second;
+    hipEventRecord(*a, s);
+}
+static void timer_end(wt_engine* e, EvTimer& t, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+    if (!a) return;
+    hipEventRecord(b, s);
+    t.pending.push_back({a, b});
+}
+static void timer_collect(EvTimer& t) {
+    for (auto& pr : t.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            t.ms += ms;
+            t.launches += 1;
+        }
+        t.pool.push_back(pr);
+    }
+    t.pending.clear();
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------- open / close
+extern "C" int wt_abi_version(void) { return WT_ABI_VERSION; }
+extern "C" const char* wt_last_error(void) { return g_err; }
+
+extern "C" void wt_engine_close(wt_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) {
+        timer_collect(*t);
+        for (auto& pr : t->pool) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    }
+    if (e->ev_in) hipEventDestroy(e->ev_in);
+    if (e->ev_out) hipEventDestroy(e->ev_out);
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
+    if (e->h_state) hipHostFree(e->h_state);
+    if (e->enc_ws) hipFree(e->enc_ws);
+    if (e->dec_ws) hipFree(e->dec_ws);
+    if (e->weights_base) hipFree(e->weights_base);
+    delete e;
+}
+
+extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_engine** out) {
+    if (!blob || !out) return fail(WT_E_INVALID, "wt_engine_open: null argument");
+    *out = nullptr;
+    if (nbytes < sizeof(BlobHeader)) return fail(WT_E_INVALID, "engine blob too small (%zu bytes)", nbytes);
+    BlobHeader hd;
+    memcpy(&hd, blob, sizeof hd);
+    if (memcmp(hd.magic, "WTENGINE", 8) != 0) return fail(WT_E_INVALID, "engine blob has bad magic");
+    if (hd.version != 1) return fail(WT_E_UNSUPPORTED, "engine blob version %u not supported", hd.version);
+    if (hd.total_bytes != nbytes || hd.table_off + (uint64_t)hd.n_tensors * sizeof(BlobTensor) > nbytes ||
+        hd.data_off > nbytes)
+        return fail(WT_E_INVALID, "engine blob is truncated or corrupt (header says %llu bytes, got %zu)",
+                    (unsigned long long)hd.total_bytes, nbytes);
+    if (hd.kind != WT_KIND_ENCODER && hd.kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "unknown engine kind %u", hd.kind);
+    if (hd.precision != WT_F32)
+        return fail(WT_E_UNSUPPORTED, "engine precision %u: only float32 engines are implemented", hd.precision);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(WT_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+
+    wt_engine* e = new wt_engine();
+    e->kind = (int)hd.kind;
+    e->device = device;
+    e->d = hd.cfg[CFG_D_MODEL]; e->H = hd.cfg[CFG_HEADS]; e->L = hd.cfg[CFG_LAYERS]; e->F = hd.cfg[CFG_FFN];
+    e->C = hd.cfg[CFG_MELS]; e->S = hd.cfg[CFG_SRC_POS]; e->T = hd.cfg[CFG_TGT_POS]; e->V = hd.cfg[CFG_VOCAB];
+    auto bad = [&](const char* why) {
+        int rc = fail(WT_E_INVALID, "engine config invalid: %s (d=%d H=%d L=%d F=%d C=%d S=%d T=%d V=%d)", why, e->d,
+                      e->H, e->L, e->F, e->C, e->S, e->T, e->V);
+        wt_engine_close(e);
+        return rc;
+    };
+    if (e->d <= 0 || e->H <= 0 || e->d != e->H * HEAD_DIM) return bad("head_dim must be 64");
+    if (e->d > 1024 || (e->d & 3)) return bad("d_model must be a multiple of 4 and <= 1024");
+    if (e->L <= 0 || e->F <= 0 || (e->F & 3) || e->F > 4096) return bad("ffn_dim must be a multiple of 4 and <= 4096");
+    if (e->S <= 0 || e->C <= 0 || e->C > 128 || (e->C & 3)) return bad("num_mel_bins must be a multiple of 4 and <= 128");
+    if (e->kind == WT_KIND_DECODER && (e->T <= 1 || e->V <= 0)) return bad("decoder needs max_target_positions and vocab");
+
+    // upload the tensor payload in one allocation
+    const size_t payload = nbytes - hd.data_off;
+    hipError_t he = hipMalloc((void**)&e->weights_base, payload ? payload : 256);
+    if (he != hipSuccess) {
+        int rc = fail(WT_E_NOMEM, "hipMalloc(%zu) for weights failed: %s", payload, hipGetErrorString(he));
+        wt_engine_close(e);
+        return rc;
+    }
+    he = hipMemcpy(e->weights_base, (const char*)blob + hd.data_off, payload, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        int rc = fail(WT_E_HIP, "weight upload failed: %s", hipGetErrorString(he));
+        wt_engine_close(e);
+        return rc;
+    }
+    const BlobTensor* tab = (const BlobTensor*)((const char*)blob + hd.table_off);
+    for (uint32_t i = 0; i < hd.n_tensors; ++i) {
+        BlobTensor bt;
+        memcpy(&bt, tab + i, sizeof bt);
+        bt.name[sizeof(bt.name) - 1] = 0;
+        if (bt.offset < hd.data_off || bt.offset + bt.nbytes > nbytes || (bt.offset & 15) || bt.dtype != WT_F32 || bt.ndim > 4) {
+            int rc = fail(WT_E_INVALID, "tensor '%s' has a bad table entry", bt.name);
+            wt_engine_close(e);
+            return rc;
+        }
+        DevTensor t;
+        t.ptr = (float*)(e->weights_base + (bt.offset - hd.data_off));
+        t.ndim = (int)bt.ndim;
+        int64_t n = 1;
+        for (uint32_t k = 0; k < bt.ndim; ++k) { t.shape[k] = bt.shape[k]; n *= bt.shape[k]; }
+        if ((uint64_t)n * 4 != bt.nbytes) {
+            int rc = fail(WT_E_INVALID, "tensor '%s': shape and byte count disagree", bt.name);
+            wt_engine_close(e);
+            return rc;
+        }
+        e->w[bt.name] = t;
+    }
+    // resolve the parameter tree; every lookup failure is reported by name
+    g_err[0] = 0;
+    auto need = [&](const std::string& name, std::initializer_list<int64_t> shape) -> const float* {
+        auto it = e->w.find(name);
+        if (it == e->w.end()) { if (!g_err[0]) fail(WT_E_NOTFOUND, "engine blob has no tensor '%s'", name.c_str()); return nullptr; }
+        int k = 0;
+        bool ok = it->second.ndim == (int)shape.size();
+        for (int64_t s : shape) { ok = ok && it->second.shape[k] == s; ++k; }
+        if (!ok && !g_err[0]) fail(WT_E_INVALID, "tensor '%s' has the wrong shape for this config", name.c_str());
+        return ok ? it->second.ptr : nullptr;
+    };
+    const int64_t d = e->d, F = e->F;
+    if (e->kind == WT_KIND_ENCODER) {
+        e->conv1_w = need("conv1.weight", {d, 3 * e->C});
+        e->conv1_b = need("conv1.bias", {d});
+        e->conv2_w = need("conv2.weight", {d, 3 * d});
+        e->conv2_b = need("conv2.bias", {d});
+        e->enc_pos = need("embed_positions", {e->S, d});
+        e->enc_ln_w = need("layer_norm.weight", {d});
+        e->enc_ln_b = need("layer_norm.bias", {d});
+        for (int i = 0; i < e->L; ++i) {
+            std::string p = "layers." + std::to_string(i) + ".";
+            EncLayerW l;
+            l.ln1_w = need(p + "self_attn_layer_norm.weight", {d}); l.ln1_b = need(p + "self_attn_layer_norm.bias", {d});
+            l.qkv_w = need(p + "self_attn.qkv.weight", {3 * d, d}); l.qkv_b = need(p + "self_attn.qkv.bias", {3 * d});
+            l.o_w = need(p + "self_attn.dense.weight", {d, d}); l.o_b = need(p + "self_attn.dense.bias", {d});
+            l.ln2_w = need(p + "final_layer_norm.weight", {d}); l.ln2_b = need(p + "final_layer_norm.bias", {d});
+            l.fc1_w = need(p + "fc1.weight", {F, d}); l.fc1_b = need(p + "fc1.bias", {F});
+            l.fc2_w = need(p + "fc2.weight", {d, F}); l.fc2_b = need(p + "fc2.bias", {d});
+            e->enc_layers.push_back(l);
+        }
+    } else {
+        e->tok_emb = need("embed_tokens.weight", {e->V, d});
+        e->pos_emb = need("embed_positions.weight", {e->T, d});
+        e->proj_w = hd.cfg[CFG_TIED] ? e->tok_emb : need("proj_out.weight", {e->V, d});
+        e->dec_ln_w = need("layer_norm.weight", {d});
+        e->dec_ln_b = need("layer_norm.bias", {d});
+        for (int i = 0; i < e->L; ++i) {
+            std::string p = "layers." + std::to_string(i) + ".";
+            DecLayerW l;
+            l.ln1_w = need(p + "self_attn_layer_norm.weight", {d}); l.ln1_b = need(p + "self_attn_layer_norm.bias", {d});
+            l.qkv_w = need(p + "self_attn.qkv.weight", {3 * d, d}); l.qkv_b = need(p + "self_attn.qkv.bias", {3 * d});
+            l.o_w = need(p + "self_attn.dense.weight", {d, d}); l.o_b = need(p + "self_attn.dense.bias", {d});
+            l.ln2_w = need(p + "encoder_attn_layer_norm.weight", {d}); l.ln2_b = need(p + "encoder_attn_layer_norm.bias", {d});
+            l.cq_w = need(p + "encoder_attn.q_proj.weight", {d, d}); l.cq_b = need(p + "encoder_attn.q_proj.bias", {d});
+            l.ckv_w = need(p + "encoder_attn.kv.weight", {2 * d, d}); l.ckv_b = need(p + "encoder_attn.kv.bias", {2 * d});
+            l.co_w = need(p + "encoder_attn.dense.weight", {d, d}); l.co_b = need(p + "encoder_attn.dense.bias", {d});
+            l.ln3_w = need(p + "final_layer_norm.weight", {d}); l.ln3_b = need(p + "final_layer_norm.bias", {d});
+            l.fc1_w = need(p + "fc1.weight", {F, d}); l.fc1_b = need(p + "fc1.bias", {F});
+            l.fc2_w = need(p + "fc2.weight", {d, F}); l.fc2_b = need(p + "fc2.bias", {d});
+            e->dec_layers.push_back(l);
+        }
+    }
+    if (g_err[0]) {
+        std::string keep = g_err;
+        wt_engine_close(e);
+        snprintf(g_err, sizeof g_err, "%s", keep.c_str());
+        return WT_E_INVALID;
+    }
+    *out = e;
+    return WT_OK;
+}
+
+extern "C" int wt_engine_get_info(const wt_engine* e, wt_engine_info* out) {
+    if (!e || !out) return fail(WT_E_INVALID, "wt_engine_get_info: null argument");
+    out->kind = e->kind; out->precision = e->precision;
+    out->d_model = e->d; out->n_heads = e->H; out->n_layers = e->L; out->ffn_dim = e->F;
+    out->n_mels = e->C; out->max_source_positions = e->S; out->max_target_positions = e->T; out->vocab_size = e->V;
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- encoder
+static int enc_reserve(wt_engine* e, int B) {
+    if (B <= e->enc_cap) return WT_OK;
+    if (e->enc_ws) { hipFree(e->enc_ws); e->enc_ws = nullptr; e->enc_cap = 0; }
+    const size_t Fr = 2 * (size_t)e->S, M = (size_t)B * e->S, d = e->d;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * 4, 256); return o; };
+    const size_t o_melT = take((size_t)B * (Fr + 2) * e->C + 4 * e->C);
+    const size_t o_c1 = take((size_t)B * (Fr + 2) * d + 4 * d);
+    const size_t o_h = take(M * d), o_x = take(M * d), o_qkv = take(M * 3 * d), o_ctx = take(M * d), o_ffn = take(M * e->F);
+    hipError_t he = hipMalloc((void**)&e->enc_ws, off);
+    if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for encoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
+    e->melT = (float*)(e->enc_ws + o_melT); e->c1 = (float*)(e->enc_ws + o_c1); e->hbuf = (float*)(e->enc_ws + o_h);
+    e->xbuf = (float*)(e->enc_ws + o_x); e->qkv = (float*)(e->enc_ws + o_qkv); e->ctx = (float*)(e->enc_ws + o_ctx);
+    e->ffn = (float*)(e->enc_ws + o_ffn);
+    // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
+    HIPCHK(hipMemset(e->melT, 0, ((size_t)B * (Fr + 2) * e->C + 4 * e->C) * 4));
+    HIPCHK(hipMemset(e->c1, 0, ((size_t)B * (Fr + 2) * d + 4 * d) * 4));
+    e->enc_cap = B;
+    return WT_OK;
+}
+
+#define LAUNCH(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return fail(WT_E_HIP, "kernel launch %s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static int timed_gemm(wt_engine* e, const GemmParams& p, hipStream_t s) {
+    hipEvent_t a, b;
+    timer_begin(e, e->t_gemm, s, &a, &b);
+    LAUNCH(launch_gemm_f32(p, s));
+    timer_end(e, e->t_gemm, s, a, b);
+    return WT_OK;
+}
+
+extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* out, void* stream) {
+    if (!e || e->kind != WT_KIND_ENCODER) return fail(WT_E_INVALID, "wt_encoder_forward: not an encoder engine");
+    if (!mel || !out || B < 1) return fail(WT_E_INVALID, "wt_encoder_forward: bad arguments (batch %d)", B);
+    HIPCHK(hipSetDevice(e->device));
+    int rc = enc_reserve(e, B);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int S = e->S, Fr = 2 * S, d = e->d, C = e->C, M = B * S;
+    LAUNCH(launch_mel_transpose(mel, e->melT, B, C, Fr, s));
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    // conv1 (k=3, pad 1) + GELU as an implicit GEMM over the time-major padded mel (model.py:78,97)
+    g.A = e->melT; g.lda = C; g.a_rows_per_batch = Fr; g.a_batch_stride = (long long)(Fr + 2) * C;
+    g.W = e->conv1_w; g.bias = e->conv1_b; g.M = B * Fr; g.N = d; g.K = 3 * C; g.act = 1;
+    g.C = e->c1 + d; g.ldc = d; g.c_rows_per_batch = Fr; g.c_batch_stride = (long long)(Fr + 2) * d;
+    if ((rc = timed_gemm(e, g, s))) return rc;
+    // conv2 (k=3, stride 2, pad 1) + GELU + embed_positions, written as [B*S, d] (model.py:79,98-102)
+    memset(&g, 0, sizeof g);
+    g.A = e->c1; g.lda = 2 * d; g.a_rows_per_batch = S; g.a_batch_stride = (long long)(Fr + 2) * d;
+    g.W = e->conv2_w; g.bias = e->conv2_b; g.M = M; g.N = d; g.K = 3 * d; g.act = 1; g.pos = e->enc_pos;
+    g.C = e->hbuf; g.ldc = d; g.c_rows_per_batch = S; g.c_batch_stride = (long long)S * d;
+    if ((rc = timed_gemm(e, g, s))) return rc;
+
+    auto dense = [&](const float* A, int K, const float* Wt, const float* bias, int N, float* Cout, int act,
+                     const float* resid) {
+        GemmParams q;
+        memset(&q, 0, sizeof q);
+        q.A = A; q.lda = K; q.a_rows_per_batch = M; q.W = Wt; q.bias = bias; q.M = M; q.N = N; q.K = K; q.act = act;
+        q.C = Cout; q.ldc = N; q.c_rows_per_batch = M; q.resid = resid;
+        return timed_gemm(e, q, s);
+    };
+    for (int i = 0; i < e->L; ++i) {
+        const EncLayerW& l = e->enc_layers[i];
+        LAUNCH(launch_layernorm(e->hbuf, l.ln1_w, l.ln1_b, e->xbuf, M, d, s));
+        if ((rc = dense(e->xbuf, d, l.qkv_w, l.qkv_b, 3 * d, e->qkv, 0, nullptr))) return rc;
+        {
+            hipEvent_t a, b;
+            timer_begin(e, e->t_enc_attn, s, &a, &b);
+            LAUNCH(launch_encoder_attention(e->qkv, e->ctx, B, S, e->H, s));
+            timer_end(e, e->t_enc_attn, s, a, b);
+        }
+        if ((rc = dense(e->ctx, d, l.o_w, l.o_b, d, e->hbuf, 0, e->hbuf))) return rc;
+        LAUNCH(launch_layernorm(e->hbuf, l.ln2_w, l.ln2_b, e->xbuf, M, d, s));
+        if ((rc = dense(e->xbuf, d, l.fc1_w, l.fc1_b, e->F, e->ffn, 1, nullptr))) return rc;
+        if ((rc = dense(e->ffn, e->F, l.fc2_w, l.fc2_b, d, e->hbuf, 0, e->hbuf))) return rc;
+    }
+    LAUNCH(launch_layernorm(e->hbuf, e->enc_ln_w, e->enc_ln_b, out, M, d, s));
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- decoder
+static int dec_reserve(wt_engine* e, int B, int max_length) {
+    if (B <= e->dec_cap && max_length <= e->dec_maxlen_cap) return WT_OK;
+    if (e->dec_ws) { hipFree(e->dec_ws); e->dec_ws = nullptr; e->dec_cap = 0; }
+    e->graph_valid = false;
+    const int cap_len = max_length > e->T ? max_length : e->T;
+    const size_t d = e->d, kv_self = (size_t)e->L * B * e->H * e->T * HEAD_DIM, kv_cross = (size_t)e->L * B * e->H * e->S * HEAD_DIM;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_sk = take(kv_self * 4), o_sv = take(kv_self * 4), o_ck = take(kv_cross * 4), o_cv = take(kv_cross * 4);
+    const size_t o_h = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
+    const size_t o_part = take((size_t)B * e->H * 16 * PART_STRIDE * 4), o_lg = take((size_t)B * e->V * 4);
+    const size_t o_st = take(sizeof(DecState)), o_ids = take((size_t)B * cap_len * 4), o_unf = take((size_t)B * 4);
+    const size_t o_forced = take((size_t)(cap_len + 1) * 4), o_mask = take((size_t)e->V);
+    hipError_t he = hipMalloc((void**)&e->dec_ws, off);
+    if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for decoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
+    char* b = e->dec_ws;
+    e->self_k = (float*)(b + o_sk); e->self_v = (float*)(b + o_sv); e->cross_k = (float*)(b + o_ck); e->cross_v = (float*)(b + o_cv);
+    e->dh = (float*)(b + o_h); e->dq = (float*)(b + o_q); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
+    e->logits = (float*)(b + o_lg); e->st = (DecState*)(b + o_st); e->ids = (int*)(b + o_ids); e->unfinished = (int*)(b + o_unf);
+    e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask);
+    if (!e->h_state) HIPCHK(hipHostMalloc((void**)&e->h_state, sizeof(DecState), hipHostMallocDefault));
+    if (!e->own_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    }
+    e->dec_cap = B;
+    e->dec_maxlen_cap = cap_len;
+    return WT_OK;
+}
+
+static int pick_splits(int B, int H, int len) {
+    // enough (utterance, head, split) blocks for ~2 waves of the 256 CUs, at least ~48 keys per split
+    int n = (512 + B * H - 1) / (B * H);
+    if (n < 1) n = 1;
+    while (n > 1 && len / n < 48) --n;
+    if (n > 16) n = 16;
+    return n;
+}
+
+// one decoder step over the resident (or caller-provided) caches; every step-dependent quantity comes from *st
+struct StepIO {
+    const int* ids; int ids_ld;            // token fed to row b = ids[b*ids_ld + st->cur_len-1]
+    float *self_k, *self_v; int self_cap;  // layer stride = B*H*self_cap*64
+    float *cross_k, *cross_v;              // layer stride = B*H*S*64
+    float* logits;                         // [B][V]
+    int B, nsplit_self, nsplit_cross;
+};
+
+static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
+    const int d = e->d, B = io.B, H = e->H;
+    LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
+    SkinnyParams k;
+    DecAttnParams a;
+    for (int i = 0; i < e->L; ++i) {
+        const DecLayerW& l = e->dec_layers[i];
+        float* sk = io.self_k + (size_t)i * B * H * io.self_cap * HEAD_DIM;
+        float* sv = io.self_v + (size_t)i * B * H * io.self_cap * HEAD_DIM;
+        const float* ck = io.cross_k + (size_t)i * B * H * e->S * HEAD_DIM;
+        const float* cv = io.cross_v + (size_t)i * B * H * e->S * HEAD_DIM;
+        // --- self attention (model.py:273-281, 283-304): LN -> q|k|v, append k/v row in place, attend, out-proj + residual
+        memset(&k, 0, sizeof k);
+        k.X = e->dh; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
+        k.Y = e->dq; k.kcache = sk; k.vcache = sv; k.st = e->st; k.B = B; k.N = 3 * d; k.K = d; k.ymode = YMODE_QKV_APPEND;
+        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f;
+        LAUNCH(launch_skinny(k, s));
+        memset(&a, 0, sizeof a);
+        a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
+        a.n_split = io.nsplit_self; a.fixed_len = 0;
+        LAUNCH(launch_dec_attn(a, s));
+        memset(&k, 0, sizeof k);
+        k.X = e->part; k.xmode = XMODE_ATTN_COMBINE; k.n_split = io.nsplit_self; k.W = l.o_w; k.bias = l.o_b; k.resid = e->dh;
+        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f;
+        LAUNCH(launch_skinny(k, s));
+        // --- cross attention over the encoder memory (model.py:261-272): K/V already resident
+        memset(&k, 0, sizeof k);
+        k.X = e->dh; k.ln_w = l.ln2_w; k.ln_b = l.ln2_b; k.xmode = XMODE_LAYERNORM; k.W = l.cq_w; k.bias = l.cq_b;
+        k.Y = e->dq; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 0.125f;
+        LAUNCH(launch_skinny(k, s));
+        memset(&a, 0, sizeof a);
+        a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
+        a.n_split = io.nsplit_cross; a.fixed_len = e->S;
+        {
+            hipEvent_t ta, tb;
+            timer_begin(e, e->t_cross, s, &ta, &tb);
+            LAUNCH(launch_dec_attn(a, s));
+            timer_end(e, e->t_cross, s, ta, tb);
+        }
+        memset(&k, 0, sizeof k);
+        k.X = e->part; k.xmode = XMODE_ATTN_COMBINE; k.n_split = io.nsplit_cross; k.W = l.co_w; k.bias = l.co_b; k.resid = e->dh;
+        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f;
+        LAUNCH(launch_skinny(k, s));
+        // --- FFN (model.py:363-367)
+        memset(&k, 0, sizeof k);
+        k.X = e->dh; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
+        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f;
+        LAUNCH(launch_skinny(k, s));
+        memset(&k, 0, sizeof k);
+        k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = e->dh; k.Y = e->dh; k.st = e->st;
+        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f;
+        LAUNCH(launch_skinny(k, s));
+    }
+    // final LN + vocabulary projection (model.py:455-457; logits are the engine's 'hidden_states' output)
+    memset(&k, 0, sizeof k);
+    k.X = e->dh; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
+    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f;
+    {
+        hipEvent_t ta, tb;
+        timer_begin(e, e->t_skinny, s, &ta, &tb);
+        LAUNCH(launch_skinny(k, s));
+        timer_end(e, e->t_skinny, s, ta, tb);
+    }
+    return WT_OK;
+}
+
+static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int rows, int seq_off, float* ck, float* cv,
+                            hipStream_t s) {
+    // K/V projection of encoder rows [0, rows) of every utterance into cache rows [seq_off, seq_off+rows)
+    const int d = e->d;
+    for (int i = 0; i < e->L; ++i) {
+        const DecLayerW& l = e->dec_layers[i];
+        GemmParams g;
+        memset(&g, 0, sizeof g);
+        g.A = enc_hidden; g.lda = d; g.a_rows_per_batch = rows; g.a_batch_stride = (long long)e->S * d;
+        g.W = l.ckv_w; g.bias = l.ckv_b; g.M = B * rows; g.N = 2 * d; g.K = d;
+        g.epi = EPI_KV_HEADS; g.C = ck + (size_t)i * B * e->H * e->S * HEAD_DIM; g.C2 = cv + (size_t)i * B * e->H * e->S * HEAD_DIM;
+        g.c_rows_per_batch = rows; g.kv_heads = e->H; g.kv_cap = e->S; g.kv_seq_off = seq_off;
+        int rc = timed_gemm(e, g, s);
+        if (rc) return rc;
+    }
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, const wt_greedy_params* p, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_begin: not a decoder engine");
+    if (!enc_hidden || !p || B < 1) return fail(WT_E_INVALID, "wt_decoder_begin: bad arguments");
+    if (B > 8) return fail(WT_E_UNSUPPORTED, "wt_decoder_begin: batch %d > 8 per call; shard the batch (8 per GPU)", B);
+    if (p->max_length < 2 || p->max_length > e->T) return fail(WT_E_INVALID, "max_length %d outside [2, max_target_positions=%d]", p->max_length, e->T);
+    auto tok_ok = [&](int t) { return t >= 0 && t < e->V; };
+    if (!tok_ok(p->decoder_start_token_id) || !tok_ok(p->eos_token_id) || !tok_ok(p->pad_token_id))
+        return fail(WT_E_INVALID, "start/eos/pad token id outside the vocabulary");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = dec_reserve(e, B, p->max_length);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // token rules -> device tables (SuppressTokens / SuppressTokensAtBegin / ForceTokens)
+    std::vector<uint8_t> mask(e->V, 0);
+    for (int i = 0; i < p->n_suppress_tokens; ++i) {
+        if (!tok_ok(p->suppress_tokens[i])) return fail(WT_E_INVALID, "suppress token %d outside the vocabulary", p->suppress_tokens[i]);
+        mask[p->suppress_tokens[i]] |= 1;
+    }
+    for (int i = 0; i < p->n_begin_suppress_tokens; ++i) {
+        if (!tok_ok(p->begin_suppress_tokens[i])) return fail(WT_E_INVALID, "begin-suppress token %d outside the vocabulary", p->begin_suppress_tokens[i]);
+        mask[p->begin_suppress_tokens[i]] |= 2;
+    }
+    std::vector<int> forced(e->dec_maxlen_cap + 1, -1);
+    for (int i = 0; i < p->n_forced; ++i) {
+        const int idx = p->forced_decoder_ids[2 * i], tok = p->forced_decoder_ids[2 * i + 1];
+        if (!tok_ok(tok)) return fail(WT_E_INVALID, "forced token %d outside the vocabulary", tok);
+        if (idx >= 0 && idx <= e->dec_maxlen_cap) forced[idx] = tok;
+    }
+    HIPCHK(hipMemcpyAsync(e->mask, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->forced, forced.data(), forced.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));  // the host vectors above die at return
+    const bool same = e->begun && e->B == B && e->max_length == p->max_length && e->trace == p->logits_trace &&
+                      e->begin_index == p->begin_index && e->eos == p->eos_token_id && e->pad == p->pad_token_id &&
+                      e->force_eos_step == p->force_eos_step;
+    if (!same) e->graph_valid = false;
+    e->B = B; e->max_length = p->max_length; e->begin_index = p->begin_index; e->eos = p->eos_token_id;
+    e->pad = p->pad_token_id; e->force_eos_step = p->force_eos_step; e->trace = p->logits_trace;
+    e->nsplit_cross = pick_splits(B, e->H, e->S);
+    e->nsplit_self = pick_splits(B, e->H, e->T / 2);
+    LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
+    rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, s);
+    if (rc) return rc;
+    e->begun = true;
+    return WT_OK;
+}
+
+static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
+    StepIO io;
+    io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
+    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
+    io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
+    int rc = enqueue_step(e, io, s);
+    if (rc) return rc;
+    SelectParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.logits = e->logits; sp.mask = e->mask; sp.forced = e->forced; sp.ids = e->ids; sp.unfinished = e->unfinished;
+    sp.st = e->st; sp.trace = e->trace; sp.B = e->B; sp.V = e->V; sp.max_length = e->max_length;
+    sp.begin_index = e->begin_index; sp.eos = e->eos; sp.pad = e->pad; sp.force_eos_step = e->force_eos_step;
+    LAUNCH(launch_greedy_select(sp, s));
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_steps: not a decoder engine");
+    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_steps called before wt_decoder_begin");
+    if (n_steps <= 0) return WT_OK;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (e->profiling || !e->use_graph) {  // eager: per-kernel event timers need real launches
+        for (int i = 0; i < n_steps; ++i) {
+            int rc = enqueue_fast_step(e, s);
+            if (rc) return rc;
+        }
+        return WT_OK;
+    }
+    // graph replay on the engine's own stream (the caller's stream may be the NULL stream, which cannot be captured)
+    HIPCHK(hipEventRecord(e->ev_in, s));
+    HIPCHK(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
+    if (!e->graph_valid) {
+        if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+        HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_fast_step(e, e->own_stream);
+        hipError_t ce = hipStreamEndCapture(e->own_stream, &e->graph);
+        if (rc) return rc;
+        if (ce != hipSuccess) return fail(WT_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        HIPCHK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        e->graph_valid = true;
+    }
+    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(e->graph_exec, e->own_stream));
+    HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
+    HIPCHK(hipStreamWaitEvent(s, e->ev_out, 0));
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_poll(wt_engine* e, int* cur_len, int* n_unfinished, int* done, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER || !e->begun) return fail(WT_E_STATE, "wt_decoder_poll: no decode in flight");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(e->h_state, e->st, sizeof(DecState), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (cur_len) *cur_len = e->h_state->cur_len;
+    if (n_unfinished) *n_unfinished = e->h_state->n_unfinished;
+    if (done) *done = e->h_state->done;
+    for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) timer_collect(*t);
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_read_ids(wt_engine* e, int32_t* ids_out, int ld, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER || !e->begun) return fail(WT_E_STATE, "wt_decoder_read_ids: no decode in flight");
+    if (!ids_out || ld < e->max_length) return fail(WT_E_INVALID, "wt_decoder_read_ids: row stride %d < max_length %d", ld, e->max_length);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy2DAsync(ids_out, (size_t)ld * 4, e->ids, (size_t)e->max_length * 4, (size_t)e->max_length * 4, e->B,
+                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_greedy(wt_engine* e, const float* enc_hidden, int B, const wt_greedy_params* p, int32_t* ids_out,
+                                 int* out_len, void* stream) {
+    int rc = wt_decoder_begin(e, enc_hidden, B, p, stream);
+    if (rc) return rc;
+    int cur = 1, nu = B, done = 0;
+    while (!done) {
+        const int remaining = p->max_length - cur;
+        if (remaining <= 0) break;
+        const int chunk = remaining < 16 ? remaining : 16;  // one host round-trip per 16 tokens
+        if ((rc = wt_decoder_steps(e, chunk, stream))) return rc;
+        if ((rc = wt_decoder_poll(e, &cur, &nu, &done, stream))) return rc;
+    }
+    if (ids_out && (rc = wt_decoder_read_ids(e, ids_out, p->max_length, stream))) return rc;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (out_len) *out_len = cur;
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- Session surface
+static void set_desc(wt_tensor_desc* t, const char* name, int dtype, std::initializer_list<int64_t> shape) {
+    memset(t, 0, sizeof *t);
+    snprintf(t->name, sizeof t->name, "%s", name);
+    t->dtype = dtype;
+    t->ndim = (int)shape.size();
+    int k = 0;
+    for (int64_t s : shape) t->shape[k++] = s;
+}
+
+extern "C" int wt_engine_infer_shapes(wt_engine* e, const wt_tensor_desc* in, int n_in, wt_tensor_desc* out, int* n_out) {
+    if (!e || (!in && n_in) || !out || !n_out) return fail(WT_E_INVALID, "wt_engine_infer_shapes: null argument");
+    e->shapes_ok = false;
+    auto find = [&](const char* name) -> const wt_tensor_desc* {
+        for (int i = 0; i < n_in; ++i)
+            if (strncmp(in[i].name, name, WT_NAME_LEN) == 0) return &in[i];
+        return nullptr;
+    };
+    struct Spec { const char* name; int dtype; };
+    static const Spec enc_in[] = {{"data", WT_F32}, {"length", WT_F32}};
+    static const Spec dec_in[] = {{"data", WT_I32}, {"length", WT_I32}, {"encoder_hidden_states", WT_F32},
+                                  {"self_past_key", WT_F32}, {"self_past_value", WT_F32}, {"cross_past_key", WT_F32},
+                                  {"cross_past_value", WT_F32}, {"past_self_cache_mask", WT_F32}, {"past_cross_cache_mask", WT_F32}};
+    const Spec* specs = e->kind == WT_KIND_ENCODER ? enc_in : dec_in;
+    const int nspec = e->kind == WT_KIND_ENCODER ? 2 : 9;
+    for (int i = 0; i < n_in; ++i) {  // session.py:128-136: unknown name / wrong dtype -> error
+        const Spec* sp = nullptr;
+        for (int k = 0; k < nspec; ++k)
+            if (strncmp(in[i].name, specs[k].name, WT_NAME_LEN) == 0) sp = &specs[k];
+        if (!sp) return fail(WT_E_NOTFOUND, "Tensor:%s is not an input tensor", in[i].name);
+        if (sp->dtype != in[i].dtype) return fail(WT_E_INVALID, "Tensor:%s has wrong dtype", in[i].name);
+    }
+    auto shape_is = [](const wt_tensor_desc* t, std::initializer_list<int64_t> want) {
+        if (!t || t->ndim != (int)want.size()) return false;
+        int k = 0;
+        for (int64_t s : want) {
+            if (s >= 0 && t->shape[k] != s) return false;
+            ++k;
+        }
+        return true;
+    };
+    if (e->kind == WT_KIND_ENCODER) {
+        const wt_tensor_desc* data = find("data");
+        if (!shape_is(data, {-1, e->C, 2 * e->S}) || data->shape[0] < 1)
+            return fail(WT_E_INVALID, "encoder input 'data' must be f32 [B,%d,%d]", e->C, 2 * e->S);
+        if (*n_out < 1) return fail(WT_E_INVALID, "output descriptor capacity too small");
+        e->c_B = (int)data->shape[0];
+        set_desc(&out[0], "hidden_states", WT_F32, {data->shape[0], e->S, e->d});
+        *n_out = 1;
+        e->shapes_ok = true;
+        return WT_OK;
+    }
+    const int64_t L = e->L, H = e->H, S = e->S;
+    if (!shape_is(find("data"), {1, 1})) return fail(WT_E_INVALID, "decoder input 'data' must be i32 [1,1] (batch_size and id_len are fixed to 1, model.py:474-477)");
+    if (!shape_is(find("encoder_hidden_states"), {1, S, e->d})) return fail(WT_E_INVALID, "'encoder_hidden_states' must be f32 [1,%d,%d]", (int)S, e->d);
+    const wt_tensor_desc *spk = find("self_past_key"), *spv = find("self_past_value");
+    if (!shape_is(spk, {L, H, -1, HEAD_DIM}) || !shape_is(spv, {L, H, -1, HEAD_DIM}) || spk->shape[2] != spv->shape[2] ||
+        spk->shape[2] < 1 || spk->shape[2] > e->T + 1)
+        return fail(WT_E_INVALID, "'self_past_key/value' must be f32 [%d,%d,s,64] with 1 <= s <= %d", (int)L, (int)H, e->T + 1);
+    if (!shape_is(find("cross_past_key"), {L, H, S, HEAD_DIM}) || !shape_is(find("cross_past_value"), {L, H, S, HEAD_DIM}))
+        return fail(WT_E_INVALID, "'cross_past_key/value' must be f32 [%d,%d,%d,64]", (int)L, (int)H, (int)S);
+    const wt_tensor_desc *ms = find("past_self_cache_mask"), *mc = find("past_cross_cache_mask");
+    if (!ms || ms->ndim != 1 || ms->shape[0] < 1 || ms->shape[0] > e->T + 1)
+        return fail(WT_E_INVALID, "'past_self_cache_mask' must be f32 [m_s], 1 <= m_s <= %d", e->T + 1);
+    if (!mc || mc->ndim != 1 || mc->shape[0] < 1 || mc->shape[0] > S + 1)
+        return fail(WT_E_INVALID, "'past_cross_cache_mask' must be f32 [m_c], 1 <= m_c <= %d", (int)S + 1);
+    if (ms->shape[0] - 1 >= e->T) return fail(WT_E_INVALID, "position %d exceeds max_target_positions %d", (int)ms->shape[0] - 1, e->T);
+    if (*n_out < 5) return fail(WT_E_INVALID, "output descriptor capacity too small");
+    e->c_s = (int)spk->shape[2];
+    e->c_ms = (int)ms->shape[0];
+    e->c_mc = (int)mc->shape[0];
+    const int64_t cache_len = e->c_ms - 1 < e->c_s ? e->c_ms - 1 : e->c_s;  // model.py:278
+    set_desc(&out[0], "hidden_states", WT_F32, {1, 1, e->V});
+    set_desc(&out[1], "next_self_keys", WT_F32, {L, H, cache_len + 1, HEAD_DIM});
+    set_desc(&out[2], "next_self_values", WT_F32, {L, H, cache_len + 1, HEAD_DIM});
+    set_desc(&out[3], "next_cross_keys", WT_F32, {L, H, S, HEAD_DIM});
+    set_desc(&out[4], "next_cross_values", WT_F32, {L, H, S, HEAD_DIM});
+    *n_out = 5;
+    e->shapes_ok = true;
+    return WT_OK;
+}
+
+extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const wt_binding* out, int n_out, void* stream) {
+    if (!e) return fail(WT_E_INVALID, "wt_engine_run: null engine");
+    if (!e->shapes_ok) return fail(WT_E_STATE, "wt_engine_run: call wt_engine_infer_shapes with the current input shapes first");
+    auto get = [&](const wt_binding* arr, int n, const char* name) -> void* {
+        for (int i = 0; i < n; ++i)
+            if (arr[i].name && strcmp(arr[i].name, name) == 0) return arr[i].ptr;
+        return nullptr;
+    };
+    hipStream_t s = (hipStream_t)stream;
+    if (e->kind == WT_KIND_ENCODER) {
+        const float* data = (const float*)get(in, n_in, "data");
+        float* hs = (float*)get(out, n_out, "hidden_states");
+        if (!data || !hs) return fail(WT_E_INVALID, "encoder run needs bindings 'data' and 'hidden_states'");
+        return wt_encoder_forward(e, data, e->c_B, hs, stream);
+    }
+    // ---- decoder, by-value cache protocol of run.py:103-148 / model.py:407-470 (batch 1) ----
+    const int* data = (const int*)get(in, n_in, "data");
+    const float* enc = (const float*)get(in, n_in, "encoder_hidden_states");
+    const float* spk = (const float*)get(in, n_in, "self_past_key");
+    const float* spv = (const float*)get(in, n_in, "self_past_value");
+    const float* cpk = (const float*)get(in, n_in, "cross_past_key");
+    const float* cpv = (const float*)get(in, n_in, "cross_past_value");
+    float* logits = (float*)get(out, n_out, "hidden_states");
+    float* nsk = (float*)get(out, n_out, "next_self_keys");
+    float* nsv = (float*)get(out, n_out, "next_self_values");
+    float* nck = (float*)get(out, n_out, "next_cross_keys");
+    float* ncv = (float*)get(out, n_out, "next_cross_values");
+    if (!data || !enc || !spk || !spv || !cpk || !cpv || !logits || !nsk || !nsv || !nck || !ncv)
+        return fail(WT_E_INVALID, "decoder run is missing a binding (need 7 input tensors besides the two masks and 5 outputs)");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = dec_reserve(e, 1, e->T);
+    if (rc) return rc;
+    const int LH = e->L * e->H, S = e->S;
+    const int cache_len = e->c_ms - 1 < e->c_s ? e->c_ms - 1 : e->c_s;  // model.py:278
+    const int cross_len = e->c_mc - 1;                                    // model.py:264
+    // next_* start as copies of the used part of past_* (the reference's concat), then the step runs in place on them
+    LAUNCH(launch_copy_cache_rows(spk, nsk, LH, e->c_s, cache_len + 1, cache_len, s));
+    LAUNCH(launch_copy_cache_rows(spv, nsv, LH, e->c_s, cache_len + 1, cache_len, s));
+    LAUNCH(launch_copy_cache_rows(cpk, nck, LH, S, S, cross_len, s));
+    LAUNCH(launch_copy_cache_rows(cpv, ncv, LH, S, S, cross_len, s));
+    if (cross_len < S) {  // cur = proj(enc[0 : S - cross_len]) lands behind the kept rows (model.py:265-272)
+        rc = cross_kv_project(e, enc, 1, S - cross_len, cross_len, nck, ncv, s);
+        if (rc) return rc;
+    }
+    LAUNCH(launch_set_state(e->st, /*cur_len=*/1, /*pos=*/e->c_ms - 1, /*self_len=*/cache_len, s));
+    StepIO io;
+    io.ids = data; io.ids_ld = 1; io.self_k = nsk; io.self_v = nsv; io.self_cap = cache_len + 1;
+    io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1;
+    io.nsplit_self = pick_splits(1, e->H, cache_len + 1); io.nsplit_cross = pick_splits(1, e->H, S);
+    e->begun = false;  // the resident greedy state is clobbered by this call
+    return enqueue_step(e, io, s);
+}
+
+// ------------------------------------------------------------------------------------------------- profiling
+extern "C" int wt_engine_set_profiling(wt_engine* e, int enabled) {
+    if (!e) return fail(WT_E_INVALID, "null engine");
+    e->profiling = enabled != 0;
+    for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) {
+        timer_collect(*t);
+        t->ms = 0.0;
+        t->launches = 0;
+    }
+    return WT_OK;
+}
+extern "C" int wt_engine_get_timer(wt_engine* e, const char* which, wt_kernel_timer* out) {
+    if (!e || !which || !out) return fail(WT_E_INVALID, "null argument");
+    EvTimer* t = nullptr;
+    if (!strcmp(which, "dec_cross_attn")) t = &e->t_cross;
+    else if (!strcmp(which, "gemm_f32")) t = &e->t_gemm;
+    else if (!strcmp(which, "enc_attn")) t = &e->t_enc_attn;
+    else if (!strcmp(which, "vocab_proj")) t = &e->t_skinny;
+    else return fail(WT_E_NOTFOUND, "unknown timer '%s'", which);
+    timer_collect(*t);
+    out->ms_total = (float)t->ms;
+    out->launches = t->launches;
+    return WT_OK;
+}

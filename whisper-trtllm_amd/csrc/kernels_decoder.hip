@@ -1,0 +1,492 @@
+// Decoder-step HIP kernels for gfx950 (MI355X).  One greedy step over a batch of B utterances is
+//   embed -> per layer { LN+QKV skinny GEMM (+ in-place self-KV append) -> self decode-attention ->
+//   out-proj (+residual) -> LN+q skinny GEMM -> cross decode-attention -> out-proj (+residual) ->
+//   LN+fc1+GELU -> fc2 (+residual) } -> final LN + vocabulary projection -> logits processors + argmax.
+// Every kernel is HBM-bound (weights streamed once per step for the whole batch, K/V streamed once per
+// utterance), so the design rules are: 16-byte coalesced loads straight to registers, many loads in flight,
+// wave-level reductions with v_permlane32_swap / v_permlane16_swap / DPP, and no step-dependent kernel
+// arguments (the step counters live in DecState) so a single hipGraph replays for every token.
+//
+// Reference semantics: tensorrt_llm/models/whisper/model.py:153-304 (WhisperDecoderAttention),
+// :306-369 (WhisperDecoderLayer), :407-470 (WhisperDecoder.forward); greedy loop examples/whisper/run.py:171-227;
+// processors HF generation/logits_process.py:1281-1328.  Numerics follow the HF oracle.
+#include "wt_common.h"
+#include <type_traits>
+
+namespace wt {
+
+__device__ __forceinline__ float gelu_erf_d(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the total
+__device__ __forceinline__ float row16_allreduce_sum(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float wave_allreduce_sum_d(float v) {
+    v = row16_allreduce_sum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+// ------------------------------------------------------------------------------------------------ embed
+// x[b] = embed_tokens[ids[b][cur_len-1]] + embed_positions[pos]      (model.py:423-425; HF :1149-1156)
+__global__ __launch_bounds__(256) void dec_embed_kernel(const int* __restrict__ ids, int ids_ld,
+                                                        const float* __restrict__ tok_emb,
+                                                        const float* __restrict__ pos_emb, float* __restrict__ x, int d,
+                                                        const DecState* __restrict__ st) {
+    const int b = blockIdx.x;
+    const int tok = ids[(size_t)b * ids_ld + st->cur_len - 1];
+    const float4* te = reinterpret_cast<const float4*>(tok_emb + (size_t)tok * d);
+    const float4* pe = reinterpret_cast<const float4*>(pos_emb + (size_t)st->pos * d);
+    float4* xo = reinterpret_cast<float4*>(x + (size_t)b * d);
+    for (int i = threadIdx.x; i < (d >> 2); i += 256) {
+        float4 a = te[i], c = pe[i];
+        xo[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+}
+hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
+                            int d, const DecState* st, hipStream_t s) {
+    hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(256), 0, s, ids, ids_ld, tok_emb, pos_emb, x, d, st);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ skinny GEMM
+// y[b][n] = epi(sum_k X(b)[k] W[n][k] + bias[n]) for NB <= 8 batch rows: W is streamed from HBM exactly once.
+// A wave owns a K-slice of <= 1024 columns (the whole row when K <= 1024): its slice of all NB activation rows
+// stays in registers for the life of the kernel (NB x 4 float4), W rows arrive as coalesced 1 KiB wave loads
+// (float4 per lane), two rows per iteration with the next pair prefetched.  The 2*NB per-lane partial sums are
+// reduced across the wave by a halving butterfly (v_permlane32_swap, v_permlane16_swap, then DPP row
+// rotations), leaving each (row, batch) total in one lane, which applies the epilogue.
+// When K > 1024 the 4 waves of a block split K (nsplit = 2 or 4) and combine through LDS.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
+                                                             const int rows_per_group) {
+    __shared__ float comb[2][4][2 * NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = 4 / nsplit;
+    const int sp = wave % nsplit, grp = wave / nsplit;
+    const int ks0 = sp * KS;                       // first column of this wave's slice
+    const int kend = min(p.K, ks0 + KS);           // one past its last column
+    const long long group_id = (long long)blockIdx.x * G + grp;
+    const int row_begin = (int)min((long long)p.N, group_id * rows_per_group);
+    const int row_end = min(p.N, row_begin + rows_per_group);
+
+    // ---- activation slice -> registers -------------------------------------------------------------------
+    float4 xr[NB][4];
+    bool kok[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) kok[v] = (ks0 + 4 * lane + 256 * v) < kend;
+    if (p.xmode == XMODE_ATTN_COMBINE) {
+        // X = per-split partial attention outputs; merge the splits here (deterministic two-stage softmax reduce)
+        const int H = p.K / HEAD_DIM;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kok[v] && b < p.B) {
+                    const int k = 4 * lane + 256 * v, h = k >> 6, j = k & 63;
+                    const float* pp = p.X + ((size_t)(b * H + h) * p.n_split) * PART_STRIDE;
+                    float M = -INFINITY;
+                    for (int s = 0; s < p.n_split; ++s) M = fmaxf(M, pp[s * PART_STRIDE + 64]);
+                    float L = 0.f;
+                    for (int s = 0; s < p.n_split; ++s) {
+                        const float w = __expf(pp[s * PART_STRIDE + 64] - M);
+                        const float4 os = *reinterpret_cast<const float4*>(pp + s * PART_STRIDE + j);
+                        L = fmaf(w, pp[s * PART_STRIDE + 65], L);
+                        o.x = fmaf(w, os.x, o.x);
+                        o.y = fmaf(w, os.y, o.y);
+                        o.z = fmaf(w, os.z, o.z);
+                        o.w = fmaf(w, os.w, o.w);
+                    }
+                    const float inv = 1.0f / L;
+                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                }
+                xr[b][v] = o;
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                xr[b][v] = (kok[v] && b < p.B)
+                               ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + ks0 + 4 * lane + 256 * v)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.xmode == XMODE_LAYERNORM) {  // launcher guarantees nsplit == 1: the wave holds whole rows
+            float4 g[4], be[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                g[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                be[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s += (xr[b][v].x + xr[b][v].y) + (xr[b][v].z + xr[b][v].w);
+                const float mean = wave_allreduce_sum_d(s) / p.K;
+                float q = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (kok[v]) {
+                        float a = xr[b][v].x - mean, c = xr[b][v].y - mean, e = xr[b][v].z - mean, f = xr[b][v].w - mean;
+                        q += (a * a + c * c) + (e * e + f * f);
+                    }
+                const float rstd = rsqrtf(wave_allreduce_sum_d(q) / p.K + 1e-5f);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {  // g = beta = 0 outside the row, so padding lanes stay 0
+                    xr[b][v].x = (xr[b][v].x - mean) * rstd * g[v].x + be[v].x;
+                    xr[b][v].y = (xr[b][v].y - mean) * rstd * g[v].y + be[v].y;
+                    xr[b][v].z = (xr[b][v].z - mean) * rstd * g[v].z + be[v].z;
+                    xr[b][v].w = (xr[b][v].w - mean) * rstd * g[v].w + be[v].w;
+                }
+            }
+        }
+    }
+
+    // ---- stream W ----------------------------------------------------------------------------------------------
+    float4 wbuf[2][2][4];
+    auto wload = [&](int buf, int row) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float* wp = p.W + (size_t)min(row + r, p.N - 1) * p.K + ks0 + 4 * lane;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                wbuf[buf][r][v] = kok[v] ? *reinterpret_cast<const float4*>(wp + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // which (row, batch) total this lane ends up holding after the butterfly
+    const int rho = lane >> 4, li = lane & 15;
+    const int my_r = rho >> 1;
+    const int my_b = li + (rho & 1) * (NB / 2);
+    const bool is_out_lane = li < NB / 2;
+
+    const int niter = (rows_per_group + 1) / 2;  // identical for every wave of the block (barriers below)
+    // one iteration = two W rows; `cur` (static) is the register buffer holding them, the other one is prefetched
+    auto body = [&](auto cur_c, const int it) {
+        constexpr int cur = decltype(cur_c)::value;
+        const int row = row_begin + 2 * it;
+        const bool active = row < row_end;
+        if (active && row + 2 < row_end) wload(cur ^ 1, row + 2);
+        float out = 0.f;
+        if (active) {
+            float acc[2][NB];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float4 w = wbuf[cur][r][v];
+                        a = fmaf(w.x, xr[b][v].x, a);
+                        a = fmaf(w.y, xr[b][v].y, a);
+                        a = fmaf(w.z, xr[b][v].z, a);
+                        a = fmaf(w.w, xr[b][v].w, a);
+                    }
+                    acc[r][b] = a;
+                }
+            // butterfly stage 1 (lanes l <-> l^32): lower half-wave keeps row 0, upper half-wave row 1
+            float s1[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][b]), __float_as_uint(acc[1][b]), false, false);
+                s1[b] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+            }
+            // stage 2 (l <-> l^16): even 16-lane rows keep batch b, odd rows batch b + NB/2
+            float s2[NB / 2];
+#pragma unroll
+            for (int b = 0; b < NB / 2; ++b) {
+                auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1[b]), __float_as_uint(s1[b + NB / 2]), false, false);
+                s2[b] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+            }
+            // stage 3: total over the 16 lanes of the row; lane li < NB/2 keeps value li
+#pragma unroll
+            for (int b = 0; b < NB / 2; ++b) {
+                const float t = row16_allreduce_sum(s2[b]);
+                if (li == b) out = t;
+            }
+        }
+        float total = out;
+        bool do_epi = active && is_out_lane;
+        if (nsplit > 1) {
+            if (do_epi) comb[cur][wave][my_r * NB + my_b] = out;
+            __syncthreads();
+            do_epi = do_epi && sp == 0;  // the first wave of each K-split group finishes its rows
+            if (do_epi) {
+                total = 0.f;
+                for (int s = 0; s < nsplit; ++s) total += comb[cur][grp * nsplit + s][my_r * NB + my_b];
+            }
+        }
+        const int n = row + my_r;
+        if (do_epi && n < row_end && my_b < p.B) {
+            float v = total + (p.bias ? p.bias[n] : 0.f);
+            if (p.ymode == YMODE_PLAIN) {
+                v *= p.q_scale;
+                if (p.act) v = gelu_erf_d(v);
+                const size_t off = (size_t)my_b * p.N + n;
+                if (p.resid) v += p.resid[off];
+                p.Y[off] = v;
+            } else {  // fused q|k|v projection: q (scaled) -> Y, k/v rows appended in place at index self_len
+                const int third = n / p.d_model, nn = n - third * p.d_model;
+                if (third == 0) {
+                    p.Y[(size_t)my_b * p.d_model + nn] = v * p.q_scale;
+                } else {
+                    const int h = nn >> 6, j = nn & 63, H = p.d_model >> 6;
+                    float* cache = third == 1 ? p.kcache : p.vcache;
+                    cache[(((size_t)my_b * H + h) * p.s_cap + p.st->self_len) * HEAD_DIM + j] = v;
+                }
+            }
+        }
+    };
+    if (row_begin < row_end) wload(0, row_begin);
+    for (int it = 0; it < niter; it += 2) {
+        body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < niter) body(std::integral_constant<int, 1>{}, it + 1);
+    }
+}
+
+hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
+    if (p.B < 1 || p.B > 8 || (p.K & 3)) return hipErrorInvalidValue;
+    int nsplit = 1;
+    while (p.K / nsplit > 1024 || (p.K % nsplit)) {
+        nsplit *= 2;
+        if (nsplit > 4) return hipErrorInvalidValue;
+    }
+    const int KS = p.K / nsplit;
+    if (KS & 3) return hipErrorInvalidValue;
+    if (nsplit > 1 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;
+    const int G = 4 / nsplit;
+    const int target_groups = 2048 / nsplit;  // 256 CUs x 8 waves
+    int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
+    if (rows_per_group < 2) rows_per_group = 2;
+    const int groups = (p.N + rows_per_group - 1) / rows_per_group;
+    const int grid = (groups + G - 1) / G;
+    if (p.B <= 2)
+        hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);
+    else if (p.B <= 4)
+        hipLaunchKernelGGL(skinny_gemm_kernel<4>, dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);
+    else
+        hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ decode attention
+// One query row per (utterance, head); keys/values [S][64] fp32 streamed once.  Grid (n_split, H, B); a block's
+// 4 waves x 4 sixteen-lane rows form 16 independent online-softmax streams over interleaved keys (each
+// 16-lane row reads one 256-byte key per load, 4 keys = 1 KiB per wave instruction); the 16 stream states are
+// merged through LDS into one partial (o[64] unnormalised, m, l) per split.  The consumer (out-proj skinny GEMM)
+// merges the splits, so there are no atomics and the result is bitwise reproducible.
+__global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
+    __shared__ float sm_o[16][HEAD_DIM];
+    __shared__ float sm_m[16], sm_l[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, sid = wave * 4 + (lane >> 4);
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = p.fixed_len > 0 ? p.fixed_len : p.st->self_len + 1;
+    const int chunk = (len + p.n_split - 1) / p.n_split;
+    const int s_begin = split * chunk, s_end = min(len, s_begin + chunk);
+    const int d = p.H * HEAD_DIM;
+
+    const float4 q = *reinterpret_cast<const float4*>(p.q + (size_t)b * d + h * HEAD_DIM + 4 * c);
+    const float* kb = p.kcache + ((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + 4 * c;
+    const float* vb = p.vcache + ((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + 4 * c;
+
+    float m = -INFINITY, l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;
+    for (int s0 = s_begin + sid; s0 < s_end; s0 += 16 * U) {
+        float4 kk[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = min(s0 + 16 * u, s_end - 1);
+            kk[u] = *reinterpret_cast<const float4*>(kb + (size_t)key * HEAD_DIM);
+            vv[u] = *reinterpret_cast<const float4*>(vb + (size_t)key * HEAD_DIM);
+        }
+        float sc[U];
+        float mx = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sc[u] = row16_allreduce_sum(dot4(q, kk[u]));
+            if (s0 + 16 * u >= s_end) sc[u] = -INFINITY;
+            mx = fmaxf(mx, sc[u]);
+        }
+        // s0 < s_end, so u = 0 is always a real key and mx is finite here
+        const float alpha = __expf(m - mx);
+        l *= alpha;
+        acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pr = __expf(sc[u] - mx);
+            l += pr;
+            acc.x = fmaf(pr, vv[u].x, acc.x);
+            acc.y = fmaf(pr, vv[u].y, acc.y);
+            acc.z = fmaf(pr, vv[u].z, acc.z);
+            acc.w = fmaf(pr, vv[u].w, acc.w);
+        }
+        m = mx;
+    }
+    *reinterpret_cast<float4*>(&sm_o[sid][4 * c]) = acc;
+    if (c == 0) {
+        sm_m[sid] = m;
+        sm_l[sid] = l;
+    }
+    __syncthreads();
+    if (tid < HEAD_DIM) {
+        float M = sm_m[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) M = fmaxf(M, sm_m[i]);
+        float o = 0.f, L = 0.f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
+                o = fmaf(w, sm_o[i][tid], o);
+                L = fmaf(w, sm_l[i], L);
+            }
+        }
+        float* pp = p.part + (((size_t)b * p.H + h) * p.n_split + split) * PART_STRIDE;
+        pp[tid] = o;
+        if (tid == 0) {
+            pp[64] = M;
+            pp[65] = L;
+        }
+    }
+}
+hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(dec_attn_kernel, dim3(p.n_split, p.H, p.B), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ greedy select
+// logits processors + argmax + pad/EOS bookkeeping + append, on device (run.py:199-226; HF utils.py:1502-1526;
+// processors logits_process.py:1281-1328 in the order Suppress -> SuppressAtBegin -> Force).
+__global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams p) {
+    __shared__ float s_val[16];
+    __shared__ int s_idx[16];
+    DecState* st = p.st;
+    if (st->done) return;  // steps enqueued past the stop test are no-ops
+    const int tid = threadIdx.x, cur_len = st->cur_len, step = st->step;
+    const bool at_begin = cur_len == p.begin_index;
+    for (int b = 0; b < p.B; ++b) {
+        const float* lg = p.logits + (size_t)b * p.V;
+        float* tr = p.trace ? p.trace + ((size_t)b * (p.max_length - 1) + step) * p.V : nullptr;
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        for (int v = tid; v < p.V; v += 1024) {
+            float x = lg[v];
+            if (tr) tr[v] = x;
+            const uint8_t mk = p.mask[v];
+            if ((mk & 1) || ((mk & 2) && at_begin)) x = -INFINITY;
+            if (x > best || (x == best && v < bidx)) {
+                best = x;
+                bidx = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ov > best || (ov == best && oi < bidx)) {
+                best = ov;
+                bidx = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            s_val[tid >> 6] = best;
+            s_idx[tid >> 6] = bidx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 16; ++i)
+                if (s_val[i] > best || (s_val[i] == best && s_idx[i] < bidx)) {
+                    best = s_val[i];
+                    bidx = s_idx[i];
+                }
+            int tok = bidx;
+            const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
+            if (forced >= 0) tok = forced;
+            if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
+            if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
+            p.ids[(size_t)b * p.max_length + cur_len] = tok;
+            if (tok == p.eos) p.unfinished[b] = 0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int nu = 0;
+        for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
+        st->n_unfinished = nu;
+        st->cur_len = cur_len + 1;
+        st->pos += 1;
+        st->self_len += 1;
+        st->step = step + 1;
+        if (nu == 0 || cur_len + 1 >= p.max_length) st->done = 1;  // run.py:219-226
+    }
+}
+hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(1024), 0, s, p);
+    return hipGetLastError();
+}
+
+__global__ void dec_init_kernel(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        st->cur_len = 1;
+        st->pos = 0;
+        st->self_len = 0;
+        st->done = max_length <= 1 ? 1 : 0;
+        st->n_unfinished = B;
+        st->step = 0;
+    }
+    for (int b = t; b < B; b += blockDim.x) {
+        ids[(size_t)b * max_length] = start_token;
+        unfinished[b] = 1;
+    }
+}
+hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, hipStream_t s) {
+    hipLaunchKernelGGL(dec_init_kernel, dim3(1), dim3(64), 0, s, st, ids, unfinished, B, max_length, start_token);
+    return hipGetLastError();
+}
+
+__global__ void set_state_kernel(DecState* st, int cur_len, int pos, int self_len) {
+    st->cur_len = cur_len;
+    st->pos = pos;
+    st->self_len = self_len;
+    st->done = 0;
+    st->n_unfinished = 1;
+    st->step = 0;
+}
+hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, cur_len, pos, self_len);
+    return hipGetLastError();
+}
+
+// src [LH][src_rows][64] -> dst [LH][dst_rows][64], first n_rows rows of every (layer, head) slab
+__global__ __launch_bounds__(256) void copy_cache_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                              int LH, int src_rows, int dst_rows, int n_rows) {
+    const long long per = (long long)n_rows * 16, total = per * LH;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long lh = i / per, r = i - lh * per;
+        dst[lh * dst_rows * 16 + r] = src[lh * src_rows * 16 + r];
+    }
+}
+hipError_t launch_copy_cache_rows(const float* src, float* dst, int LH, int src_rows, int dst_rows, int n_rows,
+                                  hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    const long long total = (long long)LH * n_rows * 16;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(copy_cache_rows_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), LH, src_rows, dst_rows, n_rows);
+    return hipGetLastError();
+}
+
+}  // namespace wt

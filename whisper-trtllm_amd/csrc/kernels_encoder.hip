@@ -1,0 +1,408 @@
+// Encoder-side HIP kernels for gfx950 (MI355X): mel transpose, LayerNorm, fp32 MFMA GEMM with fused
+// bias/GELU/residual/pos-emb epilogues (also used for the two Conv1d as implicit GEMMs and for the
+// cross-attention K/V projection), and a flash-style fp32 MFMA self-attention.
+//
+// Reference semantics: tensorrt_llm/models/whisper/model.py:90-111 (WhisperEncoder.forward),
+// :48-66 (WhisperEncoderLayer), layers/attention.py:216-350; numerics follow the bundled HF oracle
+// modeling_whisper.py:569-593, :632-641, :992-1011 (erf GELU, q scaled before QK^T).
+#include "wt_common.h"
+
+namespace wt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------------ mel transpose
+// mel [B][C][F] (time contiguous, the layout of run.py's `input_features`) -> melT [B][F+2][C], row = time+1,
+// rows 0 and F+1 are the conv zero padding (written here).  Makes conv1 an implicit GEMM with K = 3*C, lda = C.
+__global__ __launch_bounds__(256) void mel_transpose_kernel(const float* __restrict__ mel, float* __restrict__ melT,
+                                                            int C, int F) {
+    __shared__ float tile[128][65];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        int c = i >> 6, tl = i & 63, t = t0 + tl;
+        tile[c][tl] = t < F ? mel[((size_t)b * C + c) * F + t] : 0.f;
+    }
+    __syncthreads();
+    float* dst = melT + (size_t)b * (F + 2) * C;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        int tl = i / C, c = i - tl * C, t = t0 + tl;
+        if (t < F) dst[(size_t)(t + 1) * C + c] = tile[c][tl];
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < C; i += 256) {
+            dst[i] = 0.f;
+            dst[(size_t)(F + 1) * C + i] = 0.f;
+        }
+}
+
+hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels, int frames, hipStream_t s) {
+    if (n_mels > 128) return hipErrorInvalidValue;
+    dim3 grid((frames + 63) / 64, B);
+    hipLaunchKernelGGL(mel_transpose_kernel, grid, dim3(256), 0, s, mel, melT, n_mels, frames);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, row held in registers (d <= 1280, d % 4 == 0), two-pass mean/variance in fp32, eps 1e-5
+// (layers/normalization.py:10; nn.LayerNorm default).
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                        int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    const int n4 = d >> 2;
+    float4 v[5];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < n4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_allreduce_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        if (c < n4) {
+            float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + bb * bb) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = rsqrtf(wave_allreduce_sum(q) / d + 1e-5f);
+    float4* yr = reinterpret_cast<float4*>(y + (size_t)row * d);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        if (c < n4) {
+            float4 g = w4[c], be = b4[c], o;
+            o.x = (v[i].x - mean) * rstd * g.x + be.x;
+            o.y = (v[i].y - mean) * rstd * g.y + be.y;
+            o.z = (v[i].z - mean) * rstd * g.z + be.z;
+            o.w = (v[i].w - mean) * rstd * g.w + be.w;
+            yr[c] = o;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s) {
+    if (d > 1280 || (d & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
+// 128x128 block tile, 4 waves in a 2x2 grid, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32 (exact fp32,
+// 64 FLOP/clk/SIMD).  A and W tiles are staged global -> registers -> LDS (rows padded by 4 floats so the
+// ds_read_b128 fragment reads are bank-conflict free), double-buffered, one barrier per K-step.
+// Fragment trick: one 32x32x2 MFMA takes k = {k0, k1} from lane halves 0/1.  Each lane reads a float4
+// A[row][8q+4h .. +3] and issues 4 MFMAs with element j, so lane half h covers k = 8q+4h+j; A and W use the
+// same k assignment, so the sum over k is complete and no repacking is needed.
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBK + 4;
+constexpr int GEMM_SMEM = 2 * 2 * GBM * GLD * (int)sizeof(float);  // 73,728 B
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+    // contiguous chunk of the tile list; inside a chunk walk groups of GROUP_M row-tiles column by column so
+    // the co-resident blocks of one XCD reuse a few A row-panels and W column-panels out of its private L2.
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * GBM, n0 = bx * GBN;
+
+    // staging map: 128 rows x 8 float4; thread -> column c4, rows r0 + 32*i
+    const int c4 = tid & 7, r0 = tid >> 3;
+    const float* aptr[4];
+    const float* wptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = min(m0 + r0 + 32 * i, p.M - 1);
+        int bb = m / p.a_rows_per_batch;
+        aptr[i] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + c4 * 4;
+        int n = min(n0 + r0 + 32 * i, p.N - 1);
+        wptr[i] = p.W + (long long)n * p.K + c4 * 4;
+    }
+    float4 ra[4], rw[4];
+    auto gload = [&](int kt) {
+        const int k = kt * GBK + c4 * 4;
+        const bool ok = k < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = ok ? *reinterpret_cast<const float4*>(aptr[i] + kt * GBK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = ok ? *reinterpret_cast<const float4*>(wptr[i] + kt * GBK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * (2 * GBM * GLD);
+        float* Ws = As + GBM * GLD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(As + (r0 + 32 * i) * GLD + c4 * 4) = ra[i];
+            *reinterpret_cast<float4*>(Ws + (r0 + 32 * i) * GLD + c4 * 4) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + GBK - 1) / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* As = smem + cur * (2 * GBM * GLD) + (wr * 64 + l31) * GLD + 4 * hh;
+        const float* Ws = smem + cur * (2 * GBM * GLD) + GBM * GLD + (wc * 64 + l31) * GLD + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < GBK / 8; ++q) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + 8 * q);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + 32 * GLD + 8 * q);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + 8 * q);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + 32 * GLD + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int n = n0 + wc * 64 + tj * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+        int kv_which = 0, kv_h = 0, kv_j = 0;
+        if (p.epi == EPI_KV_HEADS) {
+            const int dkv = p.kv_heads * HEAD_DIM;
+            kv_which = n / dkv;
+            const int nn = n - kv_which * dkv;
+            kv_h = nn / HEAD_DIM;
+            kv_j = nn - kv_h * HEAD_DIM;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m >= p.M) continue;
+                float v = acc[ti][tj][r] + bv;
+                if (p.act) v = gelu_erf(v);
+                const int cb = m / p.c_rows_per_batch, cr = m - cb * p.c_rows_per_batch;
+                if (p.pos) v += p.pos[(long long)cr * p.N + n];
+                if (p.epi == EPI_ROWMAJOR) {
+                    const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
+                    if (p.resid) v += p.resid[off];
+                    p.C[off] = v;
+                } else {
+                    float* base = kv_which ? p.C2 : p.C;
+                    base[(((long long)cb * p.kv_heads + kv_h) * p.kv_cap + cr + p.kv_seq_off) * HEAD_DIM + kv_j] = v;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3)) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(nbx * nby), dim3(256), GEMM_SMEM, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ encoder attention
+// softmax(Q K^T / 8) V per (utterance, head), S = 1500 keys, head_dim 64, no mask (layers/attention.py:308,
+// 337-345; HF :569-593).  Flash-style: scores never leave registers.  One workgroup = 128 queries (4 waves x 32),
+// K/V tiles of 64 keys double-buffered in LDS.  Both products run on v_mfma_f32_32x32x2_f32 with the
+// TRANSPOSED orientation so that the query index sits on the lane:
+//   S^T[key][query] = K . Q^T     -> lane (query, half h) holds 16 keys per 32-key tile
+//   O^T[dv][query] += V^T . P^T   -> P comes straight from the S^T accumulator registers (same lane,
+//                                    same k assignment), the row max / sum / rescale are lane-local.
+constexpr int FA_BQ = 128, FA_BKV = 64, FA_LD = 68;
+constexpr int FA_SMEM = 2 * 2 * FA_BKV * FA_LD * (int)sizeof(float);  // 69,632 B
+
+__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
+                                                          int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * FA_BQ;
+    const int d = H * HEAD_DIM, ld = 3 * d;
+    const float* base = qkv + (size_t)b * S * ld + h * HEAD_DIM;
+
+    // Q fragment (B operand of S^T): lane (query, h) holds Q[query][8q+4h .. +3], pre-scaled by 64^-0.5 (exact)
+    const int qrow = q0 + wave * 32 + l31;
+    f32x4 qf[8];
+    {
+        const float* qp = base + (size_t)min(qrow, S - 1) * ld + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            qf[q] = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+            qf[q] *= 0.125f;
+        }
+    }
+    // staging map: 64 keys x 16 float4 per matrix; thread -> column c4, rows r0 + 16*i
+    const int c4 = tid & 15, r0 = tid >> 4;
+    float4 rk[4], rv[4];
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* rp = base + (size_t)min(kv0 + r0 + 16 * i, S - 1) * ld + c4 * 4;
+            rk[i] = *reinterpret_cast<const float4*>(rp + d);
+            rv[i] = *reinterpret_cast<const float4*>(rp + 2 * d);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Ks = smem + buf * (2 * FA_BKV * FA_LD);
+        float* Vs = Ks + FA_BKV * FA_LD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(Ks + (r0 + 16 * i) * FA_LD + c4 * 4) = rk[i];
+            *reinterpret_cast<float4*>(Vs + (r0 + 16 * i) * FA_LD + c4 * 4) = rv[i];
+        }
+    };
+
+    f32x16 oT[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[0][r] = oT[1][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (S + FA_BKV - 1) / FA_BKV;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, kv0 = t * FA_BKV;
+        if (t + 1 < ntiles) gload(kv0 + FA_BKV);
+        const float* Ks = smem + cur * (2 * FA_BKV * FA_LD);
+        const float* Vs = Ks + FA_BKV * FA_LD;
+
+        f32x16 sT[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sT[0][r] = sT[1][r] = 0.f;
+        const float* kp = Ks + l31 * FA_LD + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + 8 * q);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], qf[q][j], sT[0], 0, 0, 0);
+                sT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], qf[q][j], sT[1], 0, 0, 0);
+            }
+        }
+        if (kv0 + FA_BKV > S) {  // ragged last tile: keys >= S get probability 0
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= S) sT[kt][r] = -INFINITY;
+        }
+        float mx = sT[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sT[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sT[kt][r] = __expf(sT[kt][r] - m_new);
+                ps += sT[kt][r];
+            }
+        l_run = l_run * alpha + ps;  // per-lane partial (16 of the query's 32 keys per tile); halves merged at the end
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oT[0][r] *= alpha;
+            oT[1][r] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vp = Vs + (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * FA_LD + l31;
+                oT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], sT[kt][r], oT[0], 0, 0, 0);
+                oT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], sT[kt][r], oT[1], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (qrow < S) {
+        float* op = ctx + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 o;
+                o.x = oT[tt][4 * g + 0] * inv;
+                o.y = oT[tt][4 * g + 1] * inv;
+                o.z = oT[tt][4 * g + 2] * inv;
+                o.w = oT[tt][4 * g + 3] * inv;
+                *reinterpret_cast<float4*>(op + 32 * tt + 8 * g) = o;
+            }
+    }
+}
+
+hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((S + FA_BQ - 1) / FA_BQ, H, B);
+    hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(256), FA_SMEM, s, qkv, ctx, S, H);
+    return hipGetLastError();
+}
+
+}  // namespace wt

@@ -1,0 +1,121 @@
+// Shared declarations of the MI355X Whisper engine (internal; the public ABI is include/whisper_trtllm_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wt {
+
+constexpr int HEAD_DIM = 64;  // every Whisper size uses 64-wide heads (d_model / n_heads)
+
+// ---- serialized engine ("weight pack") layout, written by whisper-trtllm_amd/engine_pack.py -------------
+// [BlobHeader][BlobTensor * n_tensors][raw tensor bytes, each 256-byte aligned]
+struct BlobHeader {
+    char magic[8];  // "WTENGINE"
+    uint32_t version, kind, precision, n_tensors;
+    int32_t cfg[24];  // see CFG_* below
+    uint64_t table_off, data_off, total_bytes;
+};
+struct BlobTensor {
+    char name[96];
+    uint32_t dtype, ndim;
+    int64_t shape[4];
+    uint64_t offset, nbytes;  // offset from blob start
+};
+static_assert(sizeof(BlobHeader) == 144, "blob header layout");
+static_assert(sizeof(BlobTensor) == 152, "blob tensor layout");
+enum { CFG_D_MODEL = 0, CFG_HEADS, CFG_LAYERS, CFG_FFN, CFG_MELS, CFG_SRC_POS, CFG_TGT_POS, CFG_VOCAB, CFG_TIED };
+
+// ---- device-resident decode state: every per-step quantity kernels need lives here so that one captured
+// hipGraph replays for every step (nothing step-dependent is baked into kernel arguments) ------------------
+struct DecState {
+    int cur_len;       // tokens in each row of `ids` so far (prompt included)
+    int pos;           // decoder position of the token being fed == number of cached self keys
+    int self_len;      // valid keys already in the self cache; the new key/value row is written at this index
+    int done;          // stop test fired (all rows EOS, or cur_len >= max_length)
+    int n_unfinished;  // rows that have not produced EOS yet
+    int step;          // 0-based count of executed steps
+    int pad0, pad1;
+};
+
+// ---- fp32 GEMM (encoder / cross-KV):  C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] ) ------------------
+struct GemmParams {
+    const float* A;       // row m at A + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda
+    const float* W;       // [N][K] row-major (nn.Linear layout, x @ W^T)
+    const float* bias;    // [N] or nullptr
+    const float* resid;   // same addressing as C, or nullptr (may alias C)
+    const float* pos;     // [c_rows_per_batch][N] added after the activation (encoder embed_positions) or nullptr
+    float* C;             // row m at C + (m / c_rows_per_batch) * c_batch_stride + (m % c_rows_per_batch) * ldc
+    float* C2;            // EPI_KV_HEADS: value cache base (C is the key cache base)
+    long long a_batch_stride, c_batch_stride;
+    int M, N, K, lda, ldc;
+    int a_rows_per_batch, c_rows_per_batch;
+    int act;              // 0 none, 1 exact-erf GELU
+    int epi;              // 0 row-major, 1 split into K/V head caches [b][h][s_cap][64]
+    int kv_heads, kv_cap, kv_seq_off;  // EPI_KV_HEADS: heads per row, cache capacity (rows), first row to write
+};
+enum { EPI_ROWMAJOR = 0, EPI_KV_HEADS = 1 };
+
+// ---- decode-step skinny GEMM:  y[b][n] = epi( sum_k X(b)[k] * W[n][k] + bias[n] ),  b < NB <= 8 -----------
+enum { XMODE_PLAIN = 0, XMODE_LAYERNORM = 1, XMODE_ATTN_COMBINE = 2 };
+enum { YMODE_PLAIN = 0, YMODE_QKV_APPEND = 1 };
+struct SkinnyParams {
+    const float* X;        // PLAIN/LAYERNORM: [B][K]; ATTN_COMBINE: partials [B][H][n_split][PART_STRIDE]
+    const float* ln_w;     // LAYERNORM gamma/beta [K]
+    const float* ln_b;
+    const float* W;        // [N][K]
+    const float* bias;     // [N] or nullptr
+    const float* resid;    // [B][N] or nullptr (may alias Y)
+    float* Y;              // PLAIN: [B][N]
+    float* kcache;         // QKV_APPEND: self key/value cache of this layer [B][H][s_cap][64]; q goes to Y [B][d]
+    float* vcache;
+    const DecState* st;
+    int B, N, K;
+    int n_split;           // ATTN_COMBINE: number of partials per (b,h)
+    int xmode;             // XMODE_*
+    int act;               // 0 none, 1 GELU
+    int ymode;
+    int d_model, s_cap;    // QKV_APPEND
+    float q_scale;         // QKV_APPEND: multiply the q third by this (head_dim^-0.5)
+};
+constexpr int PART_STRIDE = 68;  // o[64], m, l, 2 pad floats
+
+// ---- decode attention (query length 1), split over the key axis ---------------------------------------------
+struct DecAttnParams {
+    const float* q;        // [B][d] (already scaled)
+    const float* kcache;   // [B][H][s_cap][64]
+    const float* vcache;
+    float* part;           // [B][H][n_split][PART_STRIDE]
+    const DecState* st;
+    int B, H, s_cap;
+    int n_split;
+    int fixed_len;         // >0: number of keys (cross attention); 0: use st->self_len + 1
+};
+
+// launchers (kernels_*.hip)
+hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels, int frames, hipStream_t s);
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s);
+hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
+hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s);
+
+hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
+                            int d, const DecState* st, hipStream_t s);
+hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s);
+hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s);
+
+struct SelectParams {
+    const float* logits;   // [B][V]
+    const uint8_t* mask;   // [V] bit0: always suppressed, bit1: suppressed when cur_len == begin_index
+    const int* forced;     // [max_length] forced token for generation index i, or -1
+    int* ids;              // [B][max_length]
+    int* unfinished;       // [B]
+    DecState* st;
+    float* trace;          // optional [B][max_length-1][V]
+    int B, V, max_length, begin_index, eos, pad, force_eos_step;
+};
+hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s);
+hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, hipStream_t s);
+hipError_t launch_copy_cache_rows(const float* src, float* dst, int LH, int src_rows, int dst_rows, int n_rows,
+                                  hipStream_t s);
+hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s);
+
+}  // namespace wt

@@ -1,0 +1,247 @@
+"""Runtime boundary: `Session` / `TensorInfo` with the reference's surface (tensorrt_llm/runtime/session.py:28-207),
+plus the batched resident-KV fast path (`WhisperEncoderEngine`, `WhisperDecoderEngine`) behind the same C-ABI.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence
+
+from . import _dtypes as trt
+from . import _lib
+from .logger import logger
+
+
+@contextlib.contextmanager
+def _scoped_stream():
+    """Current torch stream handle; synchronised when the scope ends (session.py:14-25)."""
+    import torch
+    stream = torch.cuda.current_stream()
+    try:
+        yield stream.cuda_stream
+    finally:
+        stream.synchronize()
+
+
+@dataclass
+class TensorInfo:
+    name: str
+    dtype: trt.DataType
+    shape: tuple
+
+
+def _desc(info: TensorInfo) -> _lib.TensorDesc:
+    d = _lib.TensorDesc()
+    d.name = info.name.encode()
+    d.dtype = info.dtype.code
+    shape = tuple(int(s) for s in info.shape)
+    if len(shape) > _lib.WT_MAX_DIMS:
+        raise ValueError(f"{info.name}: rank {len(shape)} too large")
+    d.ndim = len(shape)
+    for i, s in enumerate(shape):
+        d.shape[i] = s
+    return d
+
+
+class Session:
+    """`Session.from_serialized_engine(bytes)` -> `infer_shapes` -> `run` (async) like session.py:36-178."""
+
+    def __init__(self, **kwargs):
+        self._handle = None
+        self._lib = None
+
+    def _init(self, engine_buffer, device: Optional[int] = None):
+        import torch
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("whisper-trtllm_amd needs a ROCm GPU (MI355X); there is no CPU execution path")
+        dev = torch.cuda.current_device() if device is None else device
+        buf = bytes(engine_buffer)
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.wt_engine_open(buf, len(buf), dev, ctypes.byref(handle)), "wt_engine_open")
+        self._handle = handle
+        info = _lib.EngineInfo()
+        _lib.check(self._lib.wt_engine_get_info(self._handle, ctypes.byref(info)), "wt_engine_get_info")
+        self.info = info
+        return self
+
+    @staticmethod
+    def from_serialized_engine(engine, device: Optional[int] = None) -> "Session":
+        return Session()._init(engine, device)
+
+    def __del__(self):
+        try:
+            if self._handle is not None and self._lib is not None:
+                self._lib.wt_engine_close(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def infer_shapes(self, inputs: List[TensorInfo], context=None) -> Optional[List[TensorInfo]]:
+        """Returns the output TensorInfos, or None (after logging) on a name/dtype/shape mismatch — session.py:131-136."""
+        n = len(inputs)
+        arr = (_lib.TensorDesc * max(n, 1))(*[_desc(i) for i in inputs])
+        out = (_lib.TensorDesc * 8)()
+        n_out = ctypes.c_int(8)
+        rc = self._lib.wt_engine_infer_shapes(self._handle, arr, n, out, ctypes.byref(n_out))
+        if rc != 0:
+            logger.error(_lib.last_error())
+            return None
+        return [TensorInfo(out[i].name.decode(), trt.from_code(out[i].dtype), tuple(out[i].shape[k] for k in range(out[i].ndim)))
+                for i in range(n_out.value)]
+
+    def run(self, inputs: Dict[str, Any], outputs: Dict[str, Any], stream, context=None) -> bool:
+        """Enqueue on `stream` (raw hipStream_t handle as int).  True means enqueued, not finished (session.py:159-160)."""
+        def bind(d):
+            arr = (_lib.Binding * max(len(d), 1))()
+            keep = []
+            for i, (name, t) in enumerate(d.items()):
+                ptr = t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+                nm = name.encode()
+                keep.append(nm)
+                arr[i].name, arr[i].ptr = nm, ptr
+            return arr, keep
+        a_in, k1 = bind(inputs)
+        a_out, k2 = bind(outputs)
+        rc = self._lib.wt_engine_run(self._handle, a_in, len(inputs), a_out, len(outputs), ctypes.c_void_p(stream or 0))
+        if rc != 0:
+            logger.error(_lib.last_error())
+            return False
+        return True
+
+    def _debug_run(self, inputs: Dict[str, "torch.Tensor"], context=None) -> Dict[str, "torch.Tensor"]:
+        """Synchronous convenience run with freshly allocated outputs (session.py:180-207)."""
+        import torch
+        infos = [TensorInfo(n, trt.from_torch(t.dtype), tuple(t.shape)) for n, t in inputs.items()]
+        outs = self.infer_shapes(infos)
+        if outs is None:
+            raise RuntimeError(_lib.last_error())
+        outputs = {o.name: torch.empty(tuple(o.shape), dtype=trt.torch_dtype(o.dtype), device="cuda") for o in outs}
+        with _scoped_stream() as stream:
+            if not self.run(inputs, outputs, stream):
+                raise RuntimeError(_lib.last_error())
+        return outputs
+
+
+# ----------------------------------------------------------------------------------------------- batched fast path
+class WhisperEncoderEngine:
+    """mel f32 [B, n_mels, 2*S] on the GPU -> hidden f32 [B, S, d]; asynchronous on the current torch stream."""
+
+    def __init__(self, engine_buffer, device: Optional[int] = None):
+        self.session = Session.from_serialized_engine(engine_buffer, device)
+        if self.session.info.kind != 1:
+            raise ValueError("not a WhisperEncoder engine")
+
+    def __call__(self, mel):
+        import torch
+        i = self.session.info
+        if mel.dtype != torch.float32 or mel.dim() != 3 or mel.shape[1] != i.n_mels or mel.shape[2] != 2 * i.max_source_positions:
+            raise ValueError(f"mel must be float32 [B,{i.n_mels},{2 * i.max_source_positions}], got {tuple(mel.shape)} {mel.dtype}")
+        mel = mel.contiguous()
+        out = torch.empty(mel.shape[0], i.max_source_positions, i.d_model, dtype=torch.float32, device=mel.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_encoder_forward(self.session.handle, mel.data_ptr(), mel.shape[0], out.data_ptr(),
+                                                         ctypes.c_void_p(stream)), "wt_encoder_forward")
+        return out
+
+
+def _i32_array(values: Sequence[int]):
+    vals = [int(v) for v in values]
+    return (ctypes.c_int32 * max(len(vals), 1))(*vals), len(vals)
+
+
+class WhisperDecoderEngine:
+    """Greedy decode with the KV cache resident on the device (no per-token host round trip).
+
+    `config` is the HF config dict the reference pickles into engine_dir/config.pkl (run.py:251) — the keys
+    read are those of run.py:150-169, 273, 283-284."""
+
+    def __init__(self, engine_buffer, config: dict, device: Optional[int] = None):
+        self.session = Session.from_serialized_engine(engine_buffer, device)
+        if self.session.info.kind != 2:
+            raise ValueError("not a WhisperDecoder engine")
+        self.config = config
+        self.max_batch = 8
+
+    def _params(self, max_length, force_eos_step, logits_trace):
+        cfg = self.config
+        begin_index = 1 if cfg.get("forced_bos_token_id") is None else 2          # run.py:155-156 with a 1-token prompt
+        forced = cfg.get("forced_decoder_ids") or []
+        if forced:
+            begin_index += forced[-1][0]                                           # run.py:157
+        p = _lib.GreedyParams()
+        p.decoder_start_token_id = cfg["decoder_start_token_id"]
+        p.eos_token_id, p.pad_token_id = cfg["eos_token_id"], cfg["pad_token_id"]
+        p.max_length = cfg["max_length"] if max_length is None else max_length
+        p.begin_index = begin_index
+        self._keep = []
+        for field, count, vals in (("suppress_tokens", "n_suppress_tokens", cfg.get("suppress_tokens") or []),
+                                   ("begin_suppress_tokens", "n_begin_suppress_tokens", cfg.get("begin_suppress_tokens") or []),
+                                   ("forced_decoder_ids", "n_forced", [x for pair in forced for x in pair])):
+            arr, n = _i32_array(vals)
+            self._keep.append(arr)
+            setattr(p, field, ctypes.cast(arr, ctypes.POINTER(ctypes.c_int32)))
+            setattr(p, count, n if field != "forced_decoder_ids" else n // 2)
+        p.force_eos_step = -1 if force_eos_step is None else force_eos_step
+        p.logits_trace = logits_trace.data_ptr() if logits_trace is not None else None
+        return p
+
+    def begin(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None):
+        import torch
+        i = self.session.info
+        if encoder_hidden.dtype != torch.float32 or tuple(encoder_hidden.shape[1:]) != (i.max_source_positions, i.d_model):
+            raise ValueError(f"encoder_hidden must be float32 [B,{i.max_source_positions},{i.d_model}]")
+        self._enc = encoder_hidden.contiguous()
+        self._B = self._enc.shape[0]
+        self._p = self._params(max_length, force_eos_step, logits_trace)
+        self._trace = logits_trace
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_begin(self.session.handle, self._enc.data_ptr(), self._B, ctypes.byref(self._p),
+                                                       ctypes.c_void_p(stream)), "wt_decoder_begin")
+
+    def steps(self, n: int):
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_steps(self.session.handle, n, ctypes.c_void_p(stream)), "wt_decoder_steps")
+
+    def poll(self):
+        import torch
+        cur, nu, done = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_poll(self.session.handle, ctypes.byref(cur), ctypes.byref(nu), ctypes.byref(done),
+                                                      ctypes.c_void_p(stream)), "wt_decoder_poll")
+        return cur.value, nu.value, bool(done.value)
+
+    def read_ids(self, cur_len: int):
+        import torch
+        ml = self._p.max_length
+        buf = torch.empty(self._B, ml, dtype=torch.int32, device=self._enc.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_read_ids(self.session.handle, buf.data_ptr(), ml, ctypes.c_void_p(stream)),
+                   "wt_decoder_read_ids")
+        return buf[:, :cur_len].clone()
+
+    def generate(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None, chunk: int = 16):
+        """== greedy_search(...) of run.py:171-227 for a batch; returns int32 ids [B, len] on the GPU."""
+        if encoder_hidden.shape[0] > self.max_batch:
+            raise ValueError(f"at most {self.max_batch} utterances per call; shard larger batches")
+        self.begin(encoder_hidden, max_length, force_eos_step, logits_trace)
+        cur, done = 1, False
+        ml = self._p.max_length
+        while not done and cur < ml:
+            self.steps(min(chunk, ml - cur))
+            cur, _nu, done = self.poll()
+        return self.read_ids(cur)
+
+    def set_profiling(self, enabled: bool):
+        _lib.check(self.session._lib.wt_engine_set_profiling(self.session.handle, int(enabled)), "wt_engine_set_profiling")
+
+    def timer(self, which: str):
+        t = _lib.KernelTimer()
+        _lib.check(self.session._lib.wt_engine_get_timer(self.session.handle, which.encode(), ctypes.byref(t)), "wt_engine_get_timer")
+        return t.ms_total, t.launches
