@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds/second of whisper-medium.en fp32 greedy decoding on MI355X.
+
+One "step" = one pass of the hot path over one batch per GPU: encoder (8 x 30 s of 80x3000 synthetic log-mel)
++ cross-KV projection + greedy decode to max_length=448 (447 decoder steps; random-init weights never emit
+EOS, so this is the natural, no-work-skipped length).  Inputs are resident in HBM before the timed region.
+Utterance batches shard embarrassingly over ranks (no data-path collective); torch.distributed is used only
+for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields `roofline` and `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def usable_cores() -> int:
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="whisper-medium.en")
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--max-length", type=int, default=448)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-decode-steps", type=int, default=6)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import whisper_trtllm_amd as w
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: there is no CPU execution path for the engine")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = w.synthetic.get_config(args.model)
+    cfg["max_length"] = args.max_length
+    B, S, d, L, H, V = args.batch, cfg["max_source_positions"], cfg["d_model"], cfg["decoder_layers"], cfg["decoder_attention_heads"], cfg["vocab_size"]
+    t0 = time.time()
+    weights = w.synthetic.make_weights(cfg, args.seed)
+    enc = w.WhisperEncoderEngine(w.convert.build_encoder_engine(cfg, weights))
+    dec = w.WhisperDecoderEngine(w.convert.build_decoder_engine(cfg, weights), cfg)
+    mel = torch.from_numpy(w.synthetic.make_mel(cfg, index=rank * B, batch=B)).cuda()
+    if rank == 0:
+        log(f"[bench] engines built in {time.time() - t0:.1f}s ({args.model}, B={B}/GPU, world {world})")
+
+    def one_pass(force_eos_step=None):
+        hidden = enc(mel)
+        return dec.generate(hidden, force_eos_step=force_eos_step)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n, **kw):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            ids = one_pass(**kw)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        barrier()
+        return el, ids
+
+    for _ in range(args.warmup):
+        ids = one_pass()
+    elapsed, ids = timed(args.steps)
+    assert ids.shape == (B, args.max_length), ids.shape
+    audio_s = 30.0 * B * world * args.steps
+    value = audio_s / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # secondary figure: LibriSpeech-like transcript length (EOS forced at decoder step 32)
+    one_pass(force_eos_step=32)
+    el32, ids32 = timed(max(1, args.steps), force_eos_step=32)
+    value_n32 = 30.0 * B * world * max(1, args.steps) / el32
+
+    out = {
+        "metric": "audio-sec/s, whisper-medium.en fp32 greedy", "value": round(value, 2), "unit": "audio-seconds/second",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} fp32 greedy, batch {B} per GPU x 30 s / 80x3000 synthetic log-mel, "
+                               f"encoder + {args.max_length - 1} decoder steps (max_length {args.max_length}), random-init weights",
+                   "batch_per_gpu": B, "decode_steps": args.max_length - 1, "sharding": f"utterance-parallel x{world}, no collective",
+                   "value_n32_decode_steps": round(value_n32, 2), "wer": None},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-kernel durations: an instrumented eager pass with hipEvents around every launch of the timed kernels
+        dec.set_profiling(True)
+        enc_lib = enc.session._lib
+        w._lib.check(enc_lib.wt_engine_set_profiling(enc.session.handle, 1), "set_profiling")
+        one_pass()
+        torch.cuda.synchronize()
+        ms_cross, n_cross = dec.timer("dec_cross_attn")
+        ms_vocab, n_vocab = dec.timer("vocab_proj")
+        import ctypes
+        kt = w._lib.KernelTimer()
+        w._lib.check(enc_lib.wt_engine_get_timer(enc.session.handle, b"gemm_f32", ctypes.byref(kt)), "get_timer")
+        ms_gemm, n_gemm = kt.ms_total, kt.launches
+        w._lib.check(enc_lib.wt_engine_get_timer(enc.session.handle, b"enc_attn", ctypes.byref(kt)), "get_timer")
+        ms_eattn, n_eattn = kt.ms_total, kt.launches
+        dec.set_profiling(False)
+        w._lib.check(enc_lib.wt_engine_set_profiling(enc.session.handle, 0), "set_profiling")
+        # dominant kernel by time: decoder cross-attention (streams the utterances' resident K/V once per step)
+        bytes_cross = B * H * S * 64 * 4 * 2          # cross-KV bytes/step/utt / L, x B utterances per launch
+        avg_cross = ms_cross / max(1, n_cross) * 1e-3
+        ach = bytes_cross / avg_cross / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, S=1500)", "achieved": round(ach, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "bytes_per_launch": bytes_cross, "avg_launch_us": round(avg_cross * 1e6, 2), "launches": int(n_cross)}
+        F_, C = cfg["encoder_ffn_dim"], cfg["num_mel_bins"]
+        enc_gemm_flop = B * (2 * 2 * S * d * 3 * C + 2 * S * d * 3 * d + cfg["encoder_layers"] * (8 * S * d * d + 4 * S * d * F_))
+        gemm_tf = enc_gemm_flop / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
+        attn_flop = B * cfg["encoder_layers"] * 4 * H * S * S * 64
+        out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(gemm_tf, 2),
+                                   "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F32_PEAK_TF, 4),
+                                   "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
+                                   "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,
+                                   "enc_attn_total_ms": round(ms_eattn, 3)}
+        vocab_bytes = V * d * 4
+        out["roofline_vocab_proj"] = {"bound": "hbm", "achieved": round(vocab_bytes / (ms_vocab / max(1, n_vocab) * 1e-3) / 1e9, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(ms_vocab / max(1, n_vocab) * 1e3, 2)}
+
+    if rank == 0 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (torch-CPU fp32 port of the reference's bundled HF path) on this box's host cores,
+        # bounded sample: 1 utterance, full encoder + a few decoder steps; per-step time extrapolated to max_length-1.
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cpu_ref
+        cores = min(usable_cores(), 64)
+        torch.set_num_threads(cores)
+        Wt = cpu_ref.to_torch(weights)
+        x = mel[:1].cpu()
+        with torch.no_grad():
+            t = time.perf_counter()
+            h = cpu_ref.encoder_forward(Wt, cfg, x)
+            t_enc = time.perf_counter() - t
+            idt = torch.full((1, 1), cfg["decoder_start_token_id"], dtype=torch.long)
+            past, t_steps = None, []
+            for i in range(args.cpu_decode_steps):
+                t = time.perf_counter()
+                lg, past = cpu_ref.decoder_forward(Wt, cfg, idt, h, past)
+                idt = lg[:, -1].argmax(-1, keepdim=True)
+                t_steps.append(time.perf_counter() - t)
+        step_avg = float(np.mean(t_steps[1:])) if len(t_steps) > 1 else t_steps[0]
+        total = t_enc + t_steps[0] + (args.max_length - 2) * step_avg
+        out["cpu_baseline"] = {"value": round(30.0 / total, 3), "unit": "audio-seconds/second", "cores": cores, "kind": "port",
+                               "sample": f"1 utterance: full encoder ({t_enc:.2f}s) + {args.cpu_decode_steps} decoder steps "
+                                         f"(first {t_steps[0]:.3f}s incl. cross-KV, then {step_avg * 1e3:.1f} ms/step), "
+                                         f"extrapolated to {args.max_length - 1} steps, batch 1 as in run.py:296-315"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

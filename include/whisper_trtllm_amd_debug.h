@@ -18,14 +18,13 @@ int wt_dbg_gemm(const float* A, int lda, const float* W, const float* bias, cons
 int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream);
 /* qkv [B*S][3*H*64] -> ctx [B*S][H*64], softmax(QK^T/8)V per head */
 int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, void* stream);
-/* Y[B][N] = act((X' W^T + bias) * scale) (+ resid); xmode 0: X'=X[B][K], 1: X'=LayerNorm(X), 2: X = decode-attention
- * partials [B][K/64][n_split][68] merged on the fly */
+/* Y[B][N] = act((X' W^T + bias) * scale) (+ resid); xmode 0: X'=X[B][K], 1: X'=LayerNorm(X) */
 int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const float* W, const float* bias,
-                  const float* resid, float* Y, int B, int N, int K, int xmode, int n_split, int act, float scale,
-                  void* stream);
-/* q [B][H*64], k/v cache [B][H][s_cap][64], first `len` rows valid -> partials [B][H][n_split][68] */
-int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int B, int H,
-                            int s_cap, int len, int n_split, void* stream);
+                  const float* resid, float* Y, int B, int N, int K, int xmode, int act, float scale, void* stream);
+/* q [B][H*64] (pre-scaled), k/v cache [B][H][s_cap][64] with the first `len` rows valid -> out [B][H*64];
+ * part: scratch [B][H][n_split][68]; cnt: int [B][H], must be zero on entry and is left zero */
+int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt, float* out,
+                            int B, int H, int s_cap, int len, int n_split, void* stream);
 
 #ifdef __cplusplus
 }

@@ -92,8 +92,8 @@ def load():
     lib.wt_dbg_gemm.argtypes = [P, I, P, P, P, P, I, I, I, I, P]
     lib.wt_dbg_layernorm.argtypes = [P, P, P, P, I, I, P]
     lib.wt_dbg_encoder_attention.argtypes = [P, P, I, I, I, P]
-    lib.wt_dbg_skinny.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P]
-    lib.wt_dbg_decode_attention.argtypes = [P, P, P, P, I, I, I, I, I, P]
+    lib.wt_dbg_skinny.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, F, P]
+    lib.wt_dbg_decode_attention.argtypes = [P, P, P, P, P, P, I, I, I, I, I, P]
     if lib.wt_abi_version() != ABI_VERSION:
         raise EngineLibraryError(f"ABI version mismatch: library {lib.wt_abi_version()}, python {ABI_VERSION}")
     _lib = lib

@@ -23,20 +23,20 @@ extern "C" int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int
     return rc_of(launch_encoder_attention(qkv, ctx, B, S, H, (hipStream_t)stream));
 }
 extern "C" int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const float* W, const float* bias,
-                             const float* resid, float* Y, int B, int N, int K, int xmode, int n_split, int act,
-                             float scale, void* stream) {
+                             const float* resid, float* Y, int B, int N, int K, int xmode, int act, float scale,
+                             void* stream) {
     SkinnyParams k;
     memset(&k, 0, sizeof k);
     k.X = X; k.ln_w = ln_w; k.ln_b = ln_b; k.W = W; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B; k.N = N; k.K = K;
-    k.xmode = xmode; k.n_split = n_split; k.act = act; k.q_scale = scale; k.ymode = YMODE_PLAIN;
+    k.xmode = xmode; k.act = act; k.q_scale = scale; k.ymode = YMODE_PLAIN;
     return rc_of(launch_skinny(k, (hipStream_t)stream));
 }
-extern "C" int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int B, int H,
-                                       int s_cap, int len, int n_split, void* stream) {
+extern "C" int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt,
+                                       float* out, int B, int H, int s_cap, int len, int n_split, void* stream) {
     if (len < 1 || len > s_cap || n_split < 1 || n_split > 16) return -22;
     DecAttnParams a;
     memset(&a, 0, sizeof a);
-    a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
+    a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.cnt = cnt; a.out = out; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
     a.fixed_len = len;
     return rc_of(launch_dec_attn(a, (hipStream_t)stream));
 }

@@ -70,7 +70,8 @@ struct wt_engine {
     int dec_cap = 0, dec_maxlen_cap = 0;
     char* dec_ws = nullptr;
     float *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
-    float *dh = nullptr, *dq = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
+    float *dh = nullptr, *dq = nullptr, *datt = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
+    int* att_cnt = nullptr;
     DecState* st = nullptr;
     int *ids = nullptr, *unfinished = nullptr, *forced = nullptr;
     uint8_t* mask = nullptr;
@@ -392,7 +393,8 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_sk = take(kv_self * 4), o_sv = take(kv_self * 4), o_ck = take(kv_cross * 4), o_cv = take(kv_cross * 4);
-    const size_t o_h = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
+    const size_t o_h = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
+    const size_t o_cnt = take((size_t)B * e->H * 4);
     const size_t o_part = take((size_t)B * e->H * 16 * PART_STRIDE * 4), o_lg = take((size_t)B * e->V * 4);
     const size_t o_st = take(sizeof(DecState)), o_ids = take((size_t)B * cap_len * 4), o_unf = take((size_t)B * 4);
     const size_t o_forced = take((size_t)(cap_len + 1) * 4), o_mask = take((size_t)e->V);
@@ -400,9 +402,10 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for decoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     char* b = e->dec_ws;
     e->self_k = (float*)(b + o_sk); e->self_v = (float*)(b + o_sv); e->cross_k = (float*)(b + o_ck); e->cross_v = (float*)(b + o_cv);
-    e->dh = (float*)(b + o_h); e->dq = (float*)(b + o_q); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
+    e->dh = (float*)(b + o_h); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
     e->logits = (float*)(b + o_lg); e->st = (DecState*)(b + o_st); e->ids = (int*)(b + o_ids); e->unfinished = (int*)(b + o_unf);
     e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask);
+    HIPCHK(hipMemset(e->att_cnt, 0, (size_t)B * e->H * 4));  // arrival tickets start (and are left) at zero
     if (!e->h_state) HIPCHK(hipHostMalloc((void**)&e->h_state, sizeof(DecState), hipHostMallocDefault));
     if (!e->own_stream) {
         HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
@@ -450,11 +453,11 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f;
         LAUNCH(launch_skinny(k, s));
         memset(&a, 0, sizeof a);
-        a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
+        a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
         a.n_split = io.nsplit_self; a.fixed_len = 0;
         LAUNCH(launch_dec_attn(a, s));
         memset(&k, 0, sizeof k);
-        k.X = e->part; k.xmode = XMODE_ATTN_COMBINE; k.n_split = io.nsplit_self; k.W = l.o_w; k.bias = l.o_b; k.resid = e->dh;
+        k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = e->dh;
         k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f;
         LAUNCH(launch_skinny(k, s));
         // --- cross attention over the encoder memory (model.py:261-272): K/V already resident
@@ -463,7 +466,7 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         k.Y = e->dq; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 0.125f;
         LAUNCH(launch_skinny(k, s));
         memset(&a, 0, sizeof a);
-        a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
+        a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
         a.n_split = io.nsplit_cross; a.fixed_len = e->S;
         {
             hipEvent_t ta, tb;
@@ -472,7 +475,7 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
             timer_end(e, e->t_cross, s, ta, tb);
         }
         memset(&k, 0, sizeof k);
-        k.X = e->part; k.xmode = XMODE_ATTN_COMBINE; k.n_split = io.nsplit_cross; k.W = l.co_w; k.bias = l.co_b; k.resid = e->dh;
+        k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = e->dh;
         k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f;
         LAUNCH(launch_skinny(k, s));
         // --- FFN (model.py:363-367)

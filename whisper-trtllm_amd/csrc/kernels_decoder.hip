@@ -26,10 +26,12 @@ __device__ __forceinline__ float row16_allreduce_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_allreduce_sum_d(float v) {
-    v = row16_allreduce_sum(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v = row16_allreduce_sum(v);  // every lane now holds the sum of its 16-lane row; add the four rows via SGPRs
+    const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+    const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+    const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+    const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
@@ -69,6 +71,7 @@ template <int NB>
 __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
                                                              const int rows_per_group) {
     __shared__ float comb[2][4][2 * NB];
+    __shared__ __attribute__((aligned(16))) float xs[NB][1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = 4 / nsplit;
     const int sp = wave % nsplit, grp = wave / nsplit;
@@ -78,79 +81,10 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
     const int row_begin = (int)min((long long)p.N, group_id * rows_per_group);
     const int row_end = min(p.N, row_begin + rows_per_group);
 
-    // ---- activation slice -> registers -------------------------------------------------------------------
     float4 xr[NB][4];
     bool kok[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) kok[v] = (ks0 + 4 * lane + 256 * v) < kend;
-    if (p.xmode == XMODE_ATTN_COMBINE) {
-        // X = per-split partial attention outputs; merge the splits here (deterministic two-stage softmax reduce)
-        const int H = p.K / HEAD_DIM;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kok[v] && b < p.B) {
-                    const int k = 4 * lane + 256 * v, h = k >> 6, j = k & 63;
-                    const float* pp = p.X + ((size_t)(b * H + h) * p.n_split) * PART_STRIDE;
-                    float M = -INFINITY;
-                    for (int s = 0; s < p.n_split; ++s) M = fmaxf(M, pp[s * PART_STRIDE + 64]);
-                    float L = 0.f;
-                    for (int s = 0; s < p.n_split; ++s) {
-                        const float w = __expf(pp[s * PART_STRIDE + 64] - M);
-                        const float4 os = *reinterpret_cast<const float4*>(pp + s * PART_STRIDE + j);
-                        L = fmaf(w, pp[s * PART_STRIDE + 65], L);
-                        o.x = fmaf(w, os.x, o.x);
-                        o.y = fmaf(w, os.y, o.y);
-                        o.z = fmaf(w, os.z, o.z);
-                        o.w = fmaf(w, os.w, o.w);
-                    }
-                    const float inv = 1.0f / L;
-                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-                }
-                xr[b][v] = o;
-            }
-    } else {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                xr[b][v] = (kok[v] && b < p.B)
-                               ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + ks0 + 4 * lane + 256 * v)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.xmode == XMODE_LAYERNORM) {  // launcher guarantees nsplit == 1: the wave holds whole rows
-            float4 g[4], be[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                g[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-                be[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float s = 0.f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) s += (xr[b][v].x + xr[b][v].y) + (xr[b][v].z + xr[b][v].w);
-                const float mean = wave_allreduce_sum_d(s) / p.K;
-                float q = 0.f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (kok[v]) {
-                        float a = xr[b][v].x - mean, c = xr[b][v].y - mean, e = xr[b][v].z - mean, f = xr[b][v].w - mean;
-                        q += (a * a + c * c) + (e * e + f * f);
-                    }
-                const float rstd = rsqrtf(wave_allreduce_sum_d(q) / p.K + 1e-5f);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {  // g = beta = 0 outside the row, so padding lanes stay 0
-                    xr[b][v].x = (xr[b][v].x - mean) * rstd * g[v].x + be[v].x;
-                    xr[b][v].y = (xr[b][v].y - mean) * rstd * g[v].y + be[v].y;
-                    xr[b][v].z = (xr[b][v].z - mean) * rstd * g[v].z + be[v].z;
-                    xr[b][v].w = (xr[b][v].w - mean) * rstd * g[v].w + be[v].w;
-                }
-            }
-        }
-    }
-
     // ---- stream W ----------------------------------------------------------------------------------------------
     float4 wbuf[2][2][4];
     auto wload = [&](int buf, int row) {
@@ -162,6 +96,60 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
                 wbuf[buf][r][v] = kok[v] ? *reinterpret_cast<const float4*>(wp + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // the first two W rows are requested before the activation prologue so their HBM latency hides under it
+    if (row_begin < row_end) wload(0, row_begin);
+
+    // ---- activation slice -> registers -------------------------------------------------------------------
+    if (nsplit == 1) {
+        // every wave of the block needs the same NB whole rows: stage them once per block through LDS.
+        // Wave w loads (and LayerNorm-s) rows w, w+4, ...; after the barrier each wave pulls all rows to registers.
+        for (int b = wave; b < NB; b += 4) {
+            float4 xv[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                xv[v] = (kok[v] && b < p.B) ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + 4 * lane + 256 * v)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.xmode == XMODE_LAYERNORM) {
+                float sum = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sum += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
+                const float mean = wave_allreduce_sum_d(sum) / p.K;
+                float q = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (kok[v]) {
+                        float a = xv[v].x - mean, c = xv[v].y - mean, e = xv[v].z - mean, f = xv[v].w - mean;
+                        q += (a * a + c * c) + (e * e + f * f);
+                    }
+                const float rstd = rsqrtf(wave_allreduce_sum_d(q) / p.K + 1e-5f);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {  // gamma = beta = 0 outside the row, so padding lanes stay 0
+                    const float4 g = kok[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 be = kok[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xv[v].x = (xv[v].x - mean) * rstd * g.x + be.x;
+                    xv[v].y = (xv[v].y - mean) * rstd * g.y + be.y;
+                    xv[v].z = (xv[v].z - mean) * rstd * g.z + be.z;
+                    xv[v].w = (xv[v].w - mean) * rstd * g.w + be.w;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&xs[b][4 * lane + 256 * v]) = xv[v];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xr[b][v] = *reinterpret_cast<const float4*>(&xs[b][4 * lane + 256 * v]);
+    } else {  // K split over the block's waves: each wave owns a different K-slice, nothing to share
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                xr[b][v] = (kok[v] && b < p.B)
+                               ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + ks0 + 4 * lane + 256 * v)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     // which (row, batch) total this lane ends up holding after the butterfly
     const int rho = lane >> 4, li = lane & 15;
     const int my_r = rho >> 1;
@@ -246,7 +234,6 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
             }
         }
     };
-    if (row_begin < row_end) wload(0, row_begin);
     for (int it = 0; it < niter; it += 2) {
         body(std::integral_constant<int, 0>{}, it);
         if (it + 1 < niter) body(std::integral_constant<int, 1>{}, it + 1);
@@ -282,8 +269,10 @@ hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
 // One query row per (utterance, head); keys/values [S][64] fp32 streamed once.  Grid (n_split, H, B); a block's
 // 4 waves x 4 sixteen-lane rows form 16 independent online-softmax streams over interleaved keys (each
 // 16-lane row reads one 256-byte key per load, 4 keys = 1 KiB per wave instruction); the 16 stream states are
-// merged through LDS into one partial (o[64] unnormalised, m, l) per split.  The consumer (out-proj skinny GEMM)
-// merges the splits, so there are no atomics and the result is bitwise reproducible.
+// merged through LDS into one partial (o[64] unnormalised, m, l) per split.  With n_split > 1 the splits of a
+// (utterance, head) are merged by whichever block arrives last (arrival ticket; partials stored write-through
+// and re-read with sc1 loads, cdna guide §6 G16 R1); the merge walks the partials in split order, so the result is bitwise reproducible
+// whatever the arrival order.  Output: normalised context rows out[b][h*64 .. +63].
 __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     __shared__ float sm_o[16][HEAD_DIM];
     __shared__ float sm_m[16], sm_l[16];
@@ -339,26 +328,57 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
         sm_l[sid] = l;
     }
     __syncthreads();
-    if (tid < HEAD_DIM) {
-        float M = sm_m[0];
+    if (wave != 0) return;  // wave-uniform: only wave 0 publishes / merges
+    float M = sm_m[0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) M = fmaxf(M, sm_m[i]);
-        float o = 0.f, L = 0.f;
-        if (M > -INFINITY) {
+    for (int i = 1; i < 16; ++i) M = fmaxf(M, sm_m[i]);
+    float o = 0.f, L = 0.f;
+    if (M > -INFINITY) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
-                o = fmaf(w, sm_o[i][tid], o);
-                L = fmaf(w, sm_l[i], L);
-            }
-        }
-        float* pp = p.part + (((size_t)b * p.H + h) * p.n_split + split) * PART_STRIDE;
-        pp[tid] = o;
-        if (tid == 0) {
-            pp[64] = M;
-            pp[65] = L;
+        for (int i = 0; i < 16; ++i) {
+            const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
+            o = fmaf(w, sm_o[i][lane], o);
+            L = fmaf(w, sm_l[i], L);
         }
     }
+    float* outp = p.out + (size_t)b * d + h * HEAD_DIM;
+    if (p.n_split == 1) {
+        outp[lane] = o / L;
+        return;
+    }
+    float* pbase = p.part + ((size_t)b * p.H + h) * p.n_split * PART_STRIDE;
+    float* pp = pbase + split * PART_STRIDE;
+    // publish (cdna guide §6 G16, write-through form): every payload word is stored sc1 by THIS wave, the wave
+    // drains its stores, then one lane takes an arrival ticket; the last arriver reads every word with sc1 loads.
+    __hip_atomic_store(pp + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+        __hip_atomic_store(pp + 64, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 65, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.cnt + b * p.H + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = ticket == p.n_split - 1;
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: keep the loads below the ticket
+    // merge in split order; EVERY load of a published word is an agent-scope relaxed load (sc1, vector path, L1 bypass)
+    float Mg = -INFINITY;
+    for (int s = 0; s < p.n_split; ++s)
+        Mg = fmaxf(Mg, __hip_atomic_load(pbase + s * PART_STRIDE + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float og = 0.f, Lg = 0.f;
+    for (int s = 0; s < p.n_split; ++s) {
+        const float ms = __hip_atomic_load(pbase + s * PART_STRIDE + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float ls = __hip_atomic_load(pbase + s * PART_STRIDE + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float os = __hip_atomic_load(pbase + s * PART_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float w = __expf(ms - Mg);  // a split with no keys has m = -inf, l = 0, o = 0 -> weight 0
+        og = fmaf(w, os, og);
+        Lg = fmaf(w, ls, Lg);
+    }
+    outp[lane] = og / Lg;
+    if (lane == 0) p.cnt[b * p.H + h] = 0;  // re-arm the ticket for the next launch (kernel boundary orders it)
 }
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     hipLaunchKernelGGL(dec_attn_kernel, dim3(p.n_split, p.H, p.B), dim3(256), 0, s, p);
@@ -367,72 +387,74 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ greedy select
 // logits processors + argmax + pad/EOS bookkeeping + append, on device (run.py:199-226; HF utils.py:1502-1526;
-// processors logits_process.py:1281-1328 in the order Suppress -> SuppressAtBegin -> Force).
+// processors logits_process.py:1281-1328 in the order Suppress -> SuppressAtBegin -> Force).  One block per
+// utterance; the shared step counters are advanced afterwards by greedy_advance_kernel.
 __global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams p) {
     __shared__ float s_val[16];
     __shared__ int s_idx[16];
-    DecState* st = p.st;
+    const DecState* st = p.st;
     if (st->done) return;  // steps enqueued past the stop test are no-ops
-    const int tid = threadIdx.x, cur_len = st->cur_len, step = st->step;
+    const int tid = threadIdx.x, b = blockIdx.x, cur_len = st->cur_len, step = st->step;
     const bool at_begin = cur_len == p.begin_index;
-    for (int b = 0; b < p.B; ++b) {
-        const float* lg = p.logits + (size_t)b * p.V;
-        float* tr = p.trace ? p.trace + ((size_t)b * (p.max_length - 1) + step) * p.V : nullptr;
-        float best = -INFINITY;
-        int bidx = 0x7fffffff;
-        for (int v = tid; v < p.V; v += 1024) {
-            float x = lg[v];
-            if (tr) tr[v] = x;
-            const uint8_t mk = p.mask[v];
-            if ((mk & 1) || ((mk & 2) && at_begin)) x = -INFINITY;
-            if (x > best || (x == best && v < bidx)) {
-                best = x;
-                bidx = v;
-            }
+    const float* lg = p.logits + (size_t)b * p.V;
+    float* tr = p.trace ? p.trace + ((size_t)b * (p.max_length - 1) + step) * p.V : nullptr;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int v = tid; v < p.V; v += 1024) {
+        float x = lg[v];
+        if (tr) tr[v] = x;
+        const uint8_t mk = p.mask[v];
+        if ((mk & 1) || ((mk & 2) && at_begin)) x = -INFINITY;
+        if (x > best || (x == best && v < bidx)) {
+            best = x;
+            bidx = v;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bidx, o);
-            if (ov > best || (ov == best && oi < bidx)) {
-                best = ov;
-                bidx = oi;
-            }
-        }
-        if ((tid & 63) == 0) {
-            s_val[tid >> 6] = best;
-            s_idx[tid >> 6] = bidx;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < 16; ++i)
-                if (s_val[i] > best || (s_val[i] == best && s_idx[i] < bidx)) {
-                    best = s_val[i];
-                    bidx = s_idx[i];
-                }
-            int tok = bidx;
-            const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
-            if (forced >= 0) tok = forced;
-            if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
-            if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
-            p.ids[(size_t)b * p.max_length + cur_len] = tok;
-            if (tok == p.eos) p.unfinished[b] = 0;
-        }
-        __syncthreads();
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ov > best || (ov == best && oi < bidx)) {
+            best = ov;
+            bidx = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        s_val[tid >> 6] = best;
+        s_idx[tid >> 6] = bidx;
+    }
+    __syncthreads();
     if (tid == 0) {
-        int nu = 0;
-        for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
-        st->n_unfinished = nu;
-        st->cur_len = cur_len + 1;
-        st->pos += 1;
-        st->self_len += 1;
-        st->step = step + 1;
-        if (nu == 0 || cur_len + 1 >= p.max_length) st->done = 1;  // run.py:219-226
+        for (int i = 1; i < 16; ++i)
+            if (s_val[i] > best || (s_val[i] == best && s_idx[i] < bidx)) {
+                best = s_val[i];
+                bidx = s_idx[i];
+            }
+        int tok = bidx;
+        const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
+        if (forced >= 0) tok = forced;
+        if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
+        if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
+        p.ids[(size_t)b * p.max_length + cur_len] = tok;
+        if (tok == p.eos) p.unfinished[b] = 0;
     }
 }
+__global__ void greedy_advance_kernel(const SelectParams p) {
+    DecState* st = p.st;
+    if (st->done) return;
+    int nu = 0;
+    for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
+    const int cur_len = st->cur_len + 1;
+    st->n_unfinished = nu;
+    st->cur_len = cur_len;
+    st->pos += 1;
+    st->self_len += 1;
+    st->step += 1;
+    if (nu == 0 || cur_len >= p.max_length) st->done = 1;  // run.py:219-226
+}
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(p.B), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(1), 0, s, p);
     return hipGetLastError();
 }
 

@@ -56,10 +56,10 @@ struct GemmParams {
 enum { EPI_ROWMAJOR = 0, EPI_KV_HEADS = 1 };
 
 // ---- decode-step skinny GEMM:  y[b][n] = epi( sum_k X(b)[k] * W[n][k] + bias[n] ),  b < NB <= 8 -----------
-enum { XMODE_PLAIN = 0, XMODE_LAYERNORM = 1, XMODE_ATTN_COMBINE = 2 };
+enum { XMODE_PLAIN = 0, XMODE_LAYERNORM = 1 };
 enum { YMODE_PLAIN = 0, YMODE_QKV_APPEND = 1 };
 struct SkinnyParams {
-    const float* X;        // PLAIN/LAYERNORM: [B][K]; ATTN_COMBINE: partials [B][H][n_split][PART_STRIDE]
+    const float* X;        // [B][K]
     const float* ln_w;     // LAYERNORM gamma/beta [K]
     const float* ln_b;
     const float* W;        // [N][K]
@@ -70,7 +70,6 @@ struct SkinnyParams {
     float* vcache;
     const DecState* st;
     int B, N, K;
-    int n_split;           // ATTN_COMBINE: number of partials per (b,h)
     int xmode;             // XMODE_*
     int act;               // 0 none, 1 GELU
     int ymode;
@@ -84,7 +83,9 @@ struct DecAttnParams {
     const float* q;        // [B][d] (already scaled)
     const float* kcache;   // [B][H][s_cap][64]
     const float* vcache;
-    float* part;           // [B][H][n_split][PART_STRIDE]
+    float* part;           // scratch [B][H][n_split][PART_STRIDE] (n_split > 1)
+    int* cnt;              // arrival tickets [B][H], zero between launches (n_split > 1)
+    float* out;            // [B][d] normalised attention output
     const DecState* st;
     int B, H, s_cap;
     int n_split;
