@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Run the engines built by build_encoder.py / build_decoder.py — the reference's examples/whisper/run.py flow.
+
+Two decode paths over the same C-ABI:
+  * Session path (default with --session): `WhisperEncoder` / `WhisperDecoder` wrappers + `greedy_search`, i.e. the
+    reference's per-token `Session.run` protocol with by-value caches (run.py:57-227), batch 1;
+  * fast path (default): resident in-place KV cache, on-device greedy loop, utterance batches of 8
+    (`WhisperEncoderEngine` / `WhisperDecoderEngine`).
+Without a dataset/processor on the box (`--synthetic N`) the inputs are seeded synthetic 80x3000 log-mels and the
+outputs are token ids."""
+import argparse
+import os
+import pickle
+import time
+
+import torch
+
+from _common import ROOT  # noqa: F401
+
+import whisper_trtllm_amd as tensorrt_llm
+from whisper_trtllm_amd import trt
+from whisper_trtllm_amd.generation import get_logits_processor, get_stopping_criteria, greedy_search
+from whisper_trtllm_amd.runtime import Session, TensorInfo, _scoped_stream
+
+_trt_to_torch_dtype_dict = {trt.float16: torch.float16, trt.float32: torch.float32, trt.int32: torch.int32, trt.int8: torch.int8}
+_torch_to_trt_dtype_dict = {v: k for k, v in _trt_to_torch_dtype_dict.items()}
+
+
+def parse_arguments():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--whisper", type=str, default="synthetic:whisper-tiny.en")
+    parser.add_argument("--engine_precision", type=str, default="float32")
+    parser.add_argument("--log_level", type=str, default="error")
+    parser.add_argument("--engine_dir", type=str, default="whisper_outputs")
+    parser.add_argument("--compare", action="store_true", help="also decode through the Session path and compare ids")
+    parser.add_argument("--session", action="store_true", help="decode through the per-token Session protocol only")
+    parser.add_argument("--synthetic", type=int, default=8, help="number of synthetic utterances")
+    parser.add_argument("--max_length", type=int, default=None)
+    return parser.parse_args()
+
+
+class WhisperEncoder:
+    """Engine wrapper with the reference's call signature (run.py:57-93): mel [1,80,3000] -> hidden [1,1500,d]."""
+
+    def __init__(self, args=None, config=None):
+        with open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb") as f:
+            self.session = Session.from_serialized_engine(f.read())
+        frames = 2 * config["max_source_positions"]
+        outputs_shape = self.session.infer_shapes([TensorInfo("data", trt.float32, (1, config["num_mel_bins"], frames)),
+                                                   TensorInfo("length", trt.float32, (1,))])
+        self.inputs = {"data": torch.rand(1, config["num_mel_bins"], frames).cuda(), "length": torch.Tensor([1.0]).cuda()}
+        self.outputs = {o.name: torch.zeros(*o.shape, dtype=_trt_to_torch_dtype_dict[o.dtype]).cuda() for o in outputs_shape}
+
+    def __call__(self, input):
+        self.inputs["data"] = input
+        with _scoped_stream() as stream:
+            ok = self.session.run(self.inputs, self.outputs, stream)
+        assert ok
+        return self.outputs["hidden_states"].clone()
+
+
+class WhisperDecoder:
+    """Per-token decoder wrapper with the by-value cache protocol of run.py:95-148 (masks carry lengths only)."""
+
+    def __init__(self, args=None, config=None):
+        self.config = config
+        with open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb") as f:
+            self.session = Session.from_serialized_engine(f.read())
+
+    def __call__(self, decoder_input_ids, encoder_outputs, past_key_values):
+        config = self.config
+        S = config["max_source_positions"]
+        inputs = {"data": decoder_input_ids.to(dtype=torch.int32, device="cuda"),
+                  "length": torch.Tensor([1.0]).to(dtype=torch.int32).cuda(),
+                  "encoder_hidden_states": encoder_outputs.to(dtype=torch.float32, device="cuda")}
+        if past_key_values is None:
+            L, H = config["decoder_layers"], config["decoder_attention_heads"]
+            dh = config["d_model"] // H
+            inputs["self_past_key"] = torch.rand(L, H, 1, dh).cuda()
+            inputs["self_past_value"] = torch.rand(L, H, 1, dh).cuda()
+            inputs["cross_past_key"] = torch.rand(L, H, S, dh).cuda()
+            inputs["cross_past_value"] = torch.rand(L, H, S, dh).cuda()
+            inputs["past_self_cache_mask"] = torch.rand(1).cuda()
+            inputs["past_cross_cache_mask"] = torch.rand(1).cuda()
+        else:
+            for name, t in zip(("self_past_key", "self_past_value", "cross_past_key", "cross_past_value"), past_key_values):
+                inputs[name] = t.to(dtype=torch.float32, device="cuda")
+            inputs["past_self_cache_mask"] = torch.rand(int(1 + past_key_values[0].shape[2]), dtype=torch.float32).cuda()
+            inputs["past_cross_cache_mask"] = torch.rand(int(1 + S), dtype=torch.float32).cuda()
+        outputs_shape = self.session.infer_shapes([TensorInfo(k, _torch_to_trt_dtype_dict[v.dtype], tuple(v.shape)) for k, v in inputs.items()])
+        outputs = {o.name: torch.zeros(*o.shape, dtype=_trt_to_torch_dtype_dict[o.dtype]).cuda() for o in outputs_shape}
+        with _scoped_stream() as stream:
+            ok = self.session.run(inputs, outputs, stream)
+        assert ok
+        return outputs["hidden_states"], (outputs["next_self_keys"], outputs["next_self_values"],
+                                          outputs["next_cross_keys"], outputs["next_cross_values"])
+
+
+def decode_with_sessions(whisperencoder, whisperdecoder, config, mel):
+    """One utterance through the reference's loop (run.py:266-284)."""
+    encoder_outputs = whisperencoder(mel)
+    input_ids = torch.Tensor([[config["decoder_start_token_id"]]]).to(dtype=torch.int32).cuda()
+    return greedy_search(model=whisperdecoder, encoder_outputs=encoder_outputs, input_ids=input_ids,
+                         logits_processor=get_logits_processor(config, input_ids.shape[-1]),
+                         stopping_criteria=get_stopping_criteria(config),
+                         pad_token_id=config["pad_token_id"], eos_token_id=config["eos_token_id"])
+
+
+if __name__ == "__main__":
+    args = parse_arguments()
+    tensorrt_llm.logger.set_level(args.log_level)
+    torch.cuda.set_device(0)
+    with open(os.path.join(args.engine_dir, "config.pkl"), "rb") as f:
+        config = pickle.load(f)
+    if args.max_length:
+        config["max_length"] = args.max_length
+    name = config.get("name", "whisper-tiny.en")
+    mels = [torch.from_numpy(tensorrt_llm.synthetic.make_mel(config, index=i, batch=1)).cuda() for i in range(args.synthetic)]
+    results = {}
+    if not args.session:
+        enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
+        dec = tensorrt_llm.WhisperDecoderEngine(open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config)
+        for _ in range(2):  # the first pass is the warm-up, as in run.py:260
+            torch.cuda.synchronize()
+            t0 = time.time()
+            ids = []
+            for b0 in range(0, len(mels), 8):
+                ids += dec.generate(enc(torch.cat(mels[b0:b0 + 8]))).cpu().tolist()
+            torch.cuda.synchronize()
+            results["fast"] = (time.time() - t0, ids)
+        print(f"fast path   : {results['fast'][0]:.3f} s for {len(mels)} x 30 s  ({30 * len(mels) / results['fast'][0]:.1f} audio-s/s)")
+    if args.session or args.compare:
+        whisperencoder, whisperdecoder = WhisperEncoder(args, config), WhisperDecoder(args, config)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            ids = [decode_with_sessions(whisperencoder, whisperdecoder, config, m)[0].cpu().tolist() for m in mels]
+            torch.cuda.synchronize()
+            results["session"] = (time.time() - t0, ids)
+        print(f"Session path: {results['session'][0]:.3f} s for {len(mels)} x 30 s  ({30 * len(mels) / results['session'][0]:.1f} audio-s/s)")
+    if args.compare:
+        a, b = results["fast"][1], results["session"][1]
+        diff = [(x, y) for x, y in zip(a, b) if x != y]
+        print(f"Compare Result: same [{len(a) - len(diff)}], diff [{len(diff)}]")
+    for key in results:
+        print(key, "ids[0][:16] =", results[key][1][0][:16])

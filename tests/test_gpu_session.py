@@ -1,0 +1,130 @@
+"""GPU: the reference's Session surface (by-value caches, mask-length gating, tensor names) through
+wt_engine_infer_shapes / wt_engine_run, against the oracle's engine-surface restatement, and the run.py flow
+(engine wrappers + Python greedy loop) against the golden ids."""
+import importlib.util
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def wt():
+    import whisper_trtllm_amd as w
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    w._lib.load()
+    return w
+
+
+def _dec_inputs(wt, cfg, tok, enc, sk, sv, ck, cv, m_s, m_c):
+    return {"data": torch.tensor([[tok]], dtype=torch.int32, device="cuda"),
+            "length": torch.tensor([1], dtype=torch.int32, device="cuda"),
+            "encoder_hidden_states": enc.cuda(), "self_past_key": sk.cuda(), "self_past_value": sv.cuda(),
+            "cross_past_key": ck.cuda(), "cross_past_value": cv.cuda(),
+            "past_self_cache_mask": torch.rand(m_s, device="cuda"), "past_cross_cache_mask": torch.rand(m_c, device="cuda")}
+
+
+@pytest.mark.parametrize("case", ["toy-short_b3", "toy-wide_b2"])
+def test_decoder_session_protocol_matches_oracle(wt, case):
+    import cpu_ref
+    z, cfg, weights, mel = load_case(case)
+    W = cpu_ref.to_torch(weights)
+    L, H, S, V = cfg["decoder_layers"], cfg["decoder_attention_heads"], cfg["max_source_positions"], cfg["vocab_size"]
+    sess = wt.Session.from_serialized_engine(wt.convert.build_decoder_engine(cfg, weights))
+    ids = z["ids"]
+    with torch.no_grad():
+        enc = cpu_ref.encoder_forward(W, cfg, torch.from_numpy(mel))[:1]
+    g = torch.Generator().manual_seed(3)
+    sk, sv = torch.rand(L, H, 1, 64, generator=g), torch.rand(L, H, 1, 64, generator=g)      # run.py:114-117 dummies
+    ck, cv = torch.rand(L, H, S, 64, generator=g), torch.rand(L, H, S, 64, generator=g)
+    m_s, m_c = 1, 1
+    for t in range(5):
+        tok = int(ids[0, t])
+        with torch.no_grad():
+            want = cpu_ref.engine_decoder_step(W, cfg, torch.tensor([[tok]], dtype=torch.int32), enc, sk, sv, ck, cv, m_s, m_c)
+        out = sess._debug_run(_dec_inputs(wt, cfg, tok, enc, sk, sv, ck, cv, m_s, m_c))
+        assert tuple(out["hidden_states"].shape) == (1, 1, V)
+        assert tuple(out["next_self_keys"].shape) == (L, H, t + 1, 64) and tuple(out["next_cross_values"].shape) == (L, H, S, 64)
+        names = ["hidden_states", "next_self_keys", "next_self_values", "next_cross_keys", "next_cross_values"]
+        for n, w_ in zip(names, want):
+            err = (out[n].cpu() - w_.reshape(out[n].shape)).abs().max().item()
+            assert err < (1e-3 if n == "hidden_states" else 1e-4), (t, n, err)
+        sk, sv, ck, cv = (out[n].cpu() for n in names[1:])
+        m_s, m_c = 1 + sk.shape[2], S + 1
+
+
+def test_decoder_session_gating_edge_cases(wt):
+    """self cache_len = min(m_s-1, s) with an over-long past; partial cross cache (model.py:264-272, :278)."""
+    import cpu_ref
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 5)
+    W = cpu_ref.to_torch(weights)
+    L, H, S, d = cfg["decoder_layers"], cfg["decoder_attention_heads"], cfg["max_source_positions"], cfg["d_model"]
+    sess = wt.Session.from_serialized_engine(wt.convert.build_decoder_engine(cfg, weights))
+    g = torch.Generator().manual_seed(1)
+    enc = torch.randn(1, S, d, generator=g)
+    for (s, m_s, m_c) in ((3, 3, 11), (6, 3, S + 1), (2, 5, 1), (1, 1, S)):
+        sk, sv = torch.randn(L, H, s, 64, generator=g), torch.randn(L, H, s, 64, generator=g)
+        ck, cv = torch.randn(L, H, S, 64, generator=g), torch.randn(L, H, S, 64, generator=g)
+        with torch.no_grad():
+            want = cpu_ref.engine_decoder_step(W, cfg, torch.tensor([[9]], dtype=torch.int32), enc, sk, sv, ck, cv, m_s, m_c)
+        out = sess._debug_run(_dec_inputs(wt, cfg, 9, enc, sk, sv, ck, cv, m_s, m_c))
+        for n, w_ in zip(["hidden_states", "next_self_keys", "next_self_values", "next_cross_keys", "next_cross_values"], want):
+            assert tuple(out[n].shape) == tuple(w_.reshape(out[n].shape).shape)
+            assert (out[n].cpu() - w_.reshape(out[n].shape)).abs().max().item() < 1e-3, (s, m_s, m_c, n)
+
+
+def test_infer_shapes_error_conventions(wt):
+    """Unknown name / wrong dtype -> logged error + None (session.py:131-136); run before infer_shapes -> False."""
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 5)
+    TI, trt = wt.TensorInfo, wt.trt
+    enc = wt.Session.from_serialized_engine(wt.convert.build_encoder_engine(cfg, weights))
+    F = 2 * cfg["max_source_positions"]
+    assert enc.run({"data": torch.zeros(1, 80, F).cuda()}, {"hidden_states": torch.zeros(1).cuda()}, 0) is False
+    assert enc.infer_shapes([TI("data", trt.float16, (1, 80, F)), TI("length", trt.float32, (1,))]) is None
+    assert enc.infer_shapes([TI("datum", trt.float32, (1, 80, F))]) is None
+    assert enc.infer_shapes([TI("data", trt.float32, (1, 80, F + 2)), TI("length", trt.float32, (1,))]) is None
+    out = enc.infer_shapes([TI("data", trt.float32, (3, 80, F)), TI("length", trt.float32, (3,))])
+    assert [(o.name, o.dtype, tuple(o.shape)) for o in out] == [("hidden_states", trt.float32, (3, cfg["max_source_positions"], cfg["d_model"]))]
+    dec = wt.Session.from_serialized_engine(wt.convert.build_decoder_engine(cfg, weights))
+    assert dec.infer_shapes([TI("data", trt.float32, (1, 1))]) is None                       # wrong dtype
+    assert dec.infer_shapes([TI("data", trt.int32, (2, 1))]) is None                          # batch is fixed to 1
+    with pytest.raises(RuntimeError):
+        wt.Session.from_serialized_engine(b"garbage" * 100)
+    with pytest.raises(ValueError):
+        wt.WhisperEncoderEngine(wt.convert.build_decoder_engine(cfg, weights))
+
+
+def test_run_py_flow_matches_golden(wt, tmp_path):
+    """examples/whisper: build_* artefacts on disk -> run.py wrappers + greedy_search (Session path) and the fast path."""
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    eng = tmp_path / "eng"
+    eng.mkdir()
+    (eng / "WhisperEncoder.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
+    (eng / "WhisperDecoder.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
+    (eng / "config.pkl").write_bytes(pickle.dumps(cfg))
+    sys.path.insert(0, os.path.join(ROOT, "examples", "whisper"))
+    spec = importlib.util.spec_from_file_location("wt_example_run", os.path.join(ROOT, "examples", "whisper", "run.py"))
+    run = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run)
+    args = types.SimpleNamespace(engine_dir=str(eng))
+    config = pickle.loads((eng / "config.pkl").read_bytes())
+    we, wd = run.WhisperEncoder(args, config), run.WhisperDecoder(args, config)
+    # batch-1 semantics of the reference: a finished row stops its own loop, so compare up to (and including) EOS
+    for b in range(mel.shape[0]):
+        got = run.decode_with_sessions(we, wd, config, torch.from_numpy(mel[b:b + 1]).cuda())[0].cpu().numpy()
+        want = z["ids"][b]
+        stop = np.where(want[1:] == cfg["eos_token_id"])[0]
+        n = (stop[0] + 2) if len(stop) else len(want)
+        np.testing.assert_array_equal(got, want[:n])

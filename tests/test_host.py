@@ -1,0 +1,164 @@
+"""CPU: host-side logic — weight-pack format, builder/parameter-tree surface, logits processors, greedy loop,
+and that the C-ABI library loads and exports every symbol its headers declare (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ref
+import whisper_trtllm_amd as wt
+from whisper_trtllm_amd import _lib, convert, engine_pack, generation, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for header in ("whisper_trtllm_amd.h", "whisper_trtllm_amd_debug.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names = set(re.findall(r"\b(wt_[a-z_0-9]+)\s*\(", text))
+        assert names, header
+        for n in sorted(names):
+            assert hasattr(lib, n), f"{n} declared in {header} but not exported"
+    assert lib.wt_abi_version() == 1
+
+
+def test_open_rejects_garbage_and_reports():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.wt_engine_open(b"x" * 10, 10, 0, ctypes.byref(h)) != 0 and "too small" in _lib.last_error()
+    blob = bytearray(convert.build_encoder_engine(synthetic.get_config("toy-short"), synthetic.make_weights(synthetic.get_config("toy-short"), 1)))
+    bad = bytes(b"NOTMAGIC" + blob[8:])
+    assert lib.wt_engine_open(bad, len(bad), 0, ctypes.byref(h)) != 0 and "magic" in _lib.last_error()
+    trunc = bytes(blob[:len(blob) // 2])
+    assert lib.wt_engine_open(trunc, len(trunc), 0, ctypes.byref(h)) != 0 and "truncated" in _lib.last_error()
+    assert not h.value
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = synthetic.get_config("toy-short")
+    blob = convert.build_encoder_engine(cfg, synthetic.make_weights(cfg, 1))
+    with pytest.raises(RuntimeError):
+        wt.Session.from_serialized_engine(blob)   # no CPU fallback anywhere in the product path
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package (or the example scripts) may import it."""
+    for top in ("whisper-trtllm_amd", "examples"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert "cpu_ref" not in src, f
+                    assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_engine_pack_roundtrip_and_layout():
+    cfg = synthetic.get_config("toy-wide")
+    W = synthetic.make_weights(cfg, 4)
+    info, t = engine_pack.unpack(convert.build_encoder_engine(cfg, W))
+    d, C = cfg["d_model"], cfg["num_mel_bins"]
+    assert info["kind"] == engine_pack.KIND_ENCODER and info["d_model"] == d and info["n_heads"] == cfg["encoder_attention_heads"]
+    # conv weights are k-major implicit-GEMM rows: w[co][k*C + ci] == conv.weight[co][ci][k]
+    c1 = W["model.encoder.conv1.weight"]
+    assert t["conv1.weight"].shape == (d, 3 * C)
+    np.testing.assert_array_equal(t["conv1.weight"][5, 2 * C + 7], c1[5, 7, 2])
+    np.testing.assert_array_equal(t["conv2.weight"][3, 1 * d + 9], W["model.encoder.conv2.weight"][3, 9, 1])
+    qkv_b = t["layers.1.self_attn.qkv.bias"]
+    np.testing.assert_array_equal(qkv_b[d:2 * d], np.zeros(d, np.float32))       # k has no bias (build_encoder.py:79)
+    np.testing.assert_array_equal(t["layers.1.self_attn.qkv.weight"][d:2 * d], W["model.encoder.layers.1.self_attn.k_proj.weight"])
+    info, t = engine_pack.unpack(convert.build_decoder_engine(cfg, W))
+    assert info["kind"] == engine_pack.KIND_DECODER and info["tied_proj_out"] == 1 and "proj_out.weight" not in t
+    np.testing.assert_array_equal(t["layers.0.encoder_attn.kv.weight"][d:], W["model.decoder.layers.0.encoder_attn.v_proj.weight"])
+    np.testing.assert_array_equal(t["layers.0.encoder_attn.kv.bias"][:d], np.zeros(d, np.float32))
+    # an untied projection is stored separately
+    W2 = dict(W)
+    W2["proj_out.weight"] = W["proj_out.weight"] + 1.0
+    info, t = engine_pack.unpack(convert.build_decoder_engine(cfg, W2))
+    assert info["tied_proj_out"] == 0 and "proj_out.weight" in t
+
+
+def test_parameter_tree_surface():
+    """Attribute paths and shape-checked `.value` assignment used by build_encoder.py:71-91 / build_decoder.py:71-101."""
+    enc = wt.models.WhisperEncoder(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256)
+    assert enc.conv1.weight.value.shape == (128, 80, 1, 3) and enc.conv2.weight.value.shape == (128, 128, 1, 3)
+    assert enc.embed_positions_weight.shape == (1, 1500, 128)
+    assert enc.layers[1].self_attn.qkv.weight.value.shape == (384, 128)
+    with pytest.raises(AssertionError):
+        enc.layers[0].fc1.weight.value = np.zeros((3, 3), np.float32)
+    names = dict(enc.named_parameters())
+    assert "layers.0.self_attn.qkv.weight" in names and "layer_norm.bias" in names and "conv1.bias" in names
+    dec = wt.models.WhisperDecoder(d_model=128, decoder_layers=2, decoder_attention_heads=2, decoder_ffn_dim=256, vocab_size=512)
+    names = dict(dec.named_parameters())
+    assert "layers.1.encoder_attn.k_proj.weight" in names and "layers.1.encoder_attn.k_proj.bias" not in names
+    assert "proj_out.weight" in names and "proj_out.bias" not in names
+    ins = dec.prepare_inputs()
+    assert [t.name for t in ins[1:]] == ["encoder_hidden_states", "self_past_key", "self_past_value", "cross_past_key",
+                                         "cross_past_value", "past_self_cache_mask", "past_cross_cache_mask"]
+    assert ins[0].data.name == "data" and ins[0].data.dtype is wt.trt.int32 and ins[2].shape == (2, 2, -1, 64)
+    with pytest.raises(RuntimeError):
+        enc(enc.prepare_inputs())               # must be traced inside net_guard
+    b = wt.Builder()
+    with pytest.raises(ValueError):
+        b.create_builder_config(precision="int4")
+    net = b.create_network()
+    assert b.build_engine(net, b.create_builder_config(precision="float32")) is None   # nothing traced -> None like the reference
+
+
+def test_logits_processors_match_oracle_rules():
+    cfg = synthetic.get_config("toy-short")
+    procs = generation.get_logits_processor(cfg, 1)
+    g = torch.Generator().manual_seed(0)
+    for cur_len in (1, 2, 3, 7):
+        ids = torch.zeros(3, cur_len, dtype=torch.long)
+        scores = torch.randn(3, cfg["vocab_size"], generator=g)
+        want = cpu_ref.apply_logits_processors(cfg, cur_len, 1, scores)
+        got = procs(ids, scores.clone())
+        assert torch.equal(torch.nan_to_num(got, neginf=-1e30), torch.nan_to_num(want, neginf=-1e30))
+    assert generation.get_stopping_criteria(cfg)(torch.zeros(1, cfg["max_length"]))
+    assert not generation.get_stopping_criteria(cfg)(torch.zeros(1, cfg["max_length"] - 1))
+
+
+def test_python_greedy_loop_equals_oracle():
+    """generation.greedy_search (the run.py:171-227 loop used on the Session path) driven by the oracle's decoder."""
+    from conftest import load_case
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    W = cpu_ref.to_torch(weights)
+    with torch.no_grad():
+        enc = cpu_ref.encoder_forward(W, cfg, torch.from_numpy(mel))
+        model = lambda ids, e, past: cpu_ref.decoder_forward(W, cfg, ids.long(), e, past)
+        start = torch.full((3, 1), cfg["decoder_start_token_id"], dtype=torch.long)
+        out = generation.greedy_search(model, enc, start, generation.get_logits_processor(cfg, 1),
+                                       generation.get_stopping_criteria(cfg), cfg["pad_token_id"], cfg["eos_token_id"])
+    np.testing.assert_array_equal(out.numpy(), z["ids"])
+
+
+def test_synthetic_weights_are_reproducible_and_complete():
+    cfg = synthetic.get_config("whisper-tiny.en")
+    names = [n for n, _, _ in synthetic.weight_specs(cfg)]
+    assert len(names) == len(set(names)) and len(names) == 4 * 15 + 4 * 24 + 7 + 4
+    a = synthetic._tensor("model.encoder.conv1.weight", (384, 80, 3), "conv", 7)
+    b = synthetic._tensor("model.encoder.conv1.weight", (384, 80, 3), "conv", 7)
+    assert a.dtype == np.float32 and np.array_equal(a, b)
+    assert not np.array_equal(a, synthetic._tensor("model.encoder.conv1.weight", (384, 80, 3), "conv", 8))
+    assert len(cfg["suppress_tokens"]) == 90 and cfg["vocab_size"] == 51864
+
+
+def test_utterance_sharding():
+    from whisper_trtllm_amd import sharding
+    for total in (0, 1, 7, 64, 73):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.utterance_shard(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.batches(3, 20, 8) == [(3, 11), (11, 19), (19, 20)]
+    with pytest.raises(ValueError):
+        sharding.utterance_shard(8, 2, 2)

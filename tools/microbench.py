@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks through the debug hooks (GPU box only): rotating operands so nothing is cache-resident
+between launches that would not be in the real pipeline (24 decoder layers -> 24 distinct weight / KV sets)."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import whisper_trtllm_amd as w  # noqa: E402
+
+lib = w._lib.load()
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, n_rot, iters=5):
+    for i in range(n_rot):
+        fn(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        for i in range(n_rot):
+            fn(i)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / (iters * n_rot)  # us per launch
+
+
+def bench_dec_attn(B=8, H=16, S=1500, L=24):
+    d = 64 * H
+    q = torch.randn(B, d, device="cuda") * 0.3
+    k = torch.randn(L, B, H, S, 64, device="cuda")
+    v = torch.randn(L, B, H, S, 64, device="cuda")
+    out = torch.empty(B, d, device="cuda")
+    cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+    mb = B * H * S * 64 * 4 * 2 / 1e6
+    for ns in (1, 2, 3, 4, 6, 8):
+        part = torch.empty(B, H, ns, 68, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_decode_attention(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), B, H, S, S, ns, ST()), L)
+        print(f"dec_attn S={S} n_split={ns}: {us:7.2f} us  {mb / us * 1e-3 * 1e3:7.1f} GB/s")
+    for length in (32, 224, 447):
+        for ns in (1, 2, 4):
+            part = torch.empty(B, H, ns, 68, device="cuda")
+            us = timeit(lambda i: lib.wt_dbg_decode_attention(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), B, H, S, length, ns, ST()), L)
+            print(f"dec_attn len={length} (cap {S}) n_split={ns}: {us:7.2f} us")
+
+
+def bench_skinny(B=8, L=24):
+    for (N, K, xmode) in ((1024, 1024, 0), (1024, 1024, 1), (3072, 1024, 1), (4096, 1024, 1), (1024, 4096, 0), (51864, 1024, 1)):
+        n_rot = L if N < 50000 else 4
+        W = torch.randn(n_rot, N, K, device="cuda") * 0.02
+        X = torch.randn(B, K, device="cuda")
+        g, be, bias = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(N, device="cuda")
+        Y = torch.empty(B, N, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_skinny(P(X), P(g), P(be), P(W[i]), P(bias), None, P(Y), B, N, K, xmode, 0, 1.0, ST()), n_rot)
+        print(f"skinny N={N} K={K} xmode={xmode}: {us:7.2f} us  {N * K * 4 / us * 1e-3:7.1f} GB/s")
+
+
+def bench_gemm(M=12000):
+    for (N, K, act) in ((3072, 1024, 0), (1024, 1024, 0), (4096, 1024, 1), (1024, 4096, 0), (2048, 1024, 0)):
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(4, N, K, device="cuda") * 0.03
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, ST()), 4, iters=3)
+        print(f"gemm M={M} N={N} K={K} act={act}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+
+
+def bench_enc_attn(B=8, S=1500, H=16):
+    qkv = torch.randn(B * S, 3 * 64 * H, device="cuda")
+    ctx = torch.empty(B * S, 64 * H, device="cuda")
+    us = timeit(lambda i: lib.wt_dbg_encoder_attention(P(qkv), P(ctx), B, S, H, ST()), 1, iters=5)
+    print(f"enc_attn B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["dec_attn", "skinny", "gemm", "enc_attn"])
+    a = ap.parse_args()
+    for name in a.what:
+        globals()["bench_" + name]()
