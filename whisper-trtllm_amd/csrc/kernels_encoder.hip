@@ -285,110 +285,146 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
     }
     // staging map: 64 keys x 16 float4 per matrix; thread -> column c4, rows r0 + 16*i
     const int c4 = tid & 15, r0 = tid >> 4;
-    float4 rk[4], rv[4];
-    auto gload = [&](int kv0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float* rp = base + (size_t)min(kv0 + r0 + 16 * i, S - 1) * ld + c4 * 4;
-            rk[i] = *reinterpret_cast<const float4*>(rp + d);
-            rv[i] = *reinterpret_cast<const float4*>(rp + 2 * d);
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* Ks = smem + buf * (2 * FA_BKV * FA_LD);
-        float* Vs = Ks + FA_BKV * FA_LD;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(Ks + (r0 + 16 * i) * FA_LD + c4 * 4) = rk[i];
-            *reinterpret_cast<float4*>(Vs + (r0 + 16 * i) * FA_LD + c4 * 4) = rv[i];
-        }
-    };
+    // staging registers as named vectors (an array here is left in scratch by hipcc: 1.2 GB of spill traffic per launch)
+    f32x4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    const float* gbase = base + c4 * 4;
+#define FA_GLOAD(kv0_)                                                                   \
+    do {                                                                                 \
+        const float* rp0 = gbase + (size_t)min((kv0_) + r0, S - 1) * ld;                 \
+        const float* rp1 = gbase + (size_t)min((kv0_) + r0 + 16, S - 1) * ld;            \
+        const float* rp2 = gbase + (size_t)min((kv0_) + r0 + 32, S - 1) * ld;            \
+        const float* rp3 = gbase + (size_t)min((kv0_) + r0 + 48, S - 1) * ld;            \
+        rk0 = *reinterpret_cast<const f32x4*>(rp0 + d); rv0 = *reinterpret_cast<const f32x4*>(rp0 + 2 * d); \
+        rk1 = *reinterpret_cast<const f32x4*>(rp1 + d); rv1 = *reinterpret_cast<const f32x4*>(rp1 + 2 * d); \
+        rk2 = *reinterpret_cast<const f32x4*>(rp2 + d); rv2 = *reinterpret_cast<const f32x4*>(rp2 + 2 * d); \
+        rk3 = *reinterpret_cast<const f32x4*>(rp3 + d); rv3 = *reinterpret_cast<const f32x4*>(rp3 + 2 * d); \
+    } while (0)
+#define FA_LSTORE(buf_)                                                                  \
+    do {                                                                                 \
+        float* Ks_ = smem + (buf_) * (2 * FA_BKV * FA_LD) + r0 * FA_LD + c4 * 4;         \
+        float* Vs_ = Ks_ + FA_BKV * FA_LD;                                               \
+        *reinterpret_cast<f32x4*>(Ks_) = rk0; *reinterpret_cast<f32x4*>(Vs_) = rv0;      \
+        *reinterpret_cast<f32x4*>(Ks_ + 16 * FA_LD) = rk1; *reinterpret_cast<f32x4*>(Vs_ + 16 * FA_LD) = rv1; \
+        *reinterpret_cast<f32x4*>(Ks_ + 32 * FA_LD) = rk2; *reinterpret_cast<f32x4*>(Vs_ + 32 * FA_LD) = rv2; \
+        *reinterpret_cast<f32x4*>(Ks_ + 48 * FA_LD) = rk3; *reinterpret_cast<f32x4*>(Vs_ + 48 * FA_LD) = rv3; \
+    } while (0)
 
-    f32x16 oT[2];
+    // named accumulators (not arrays of vectors: a runtime-looking index sends those to scratch, cdna guide rule 20)
+    f32x16 o0, o1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oT[0][r] = oT[1][r] = 0.f;
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (S + FA_BKV - 1) / FA_BKV;
-    gload(0);
-    lstore(0);
+    FA_GLOAD(0);
+    FA_LSTORE(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1, kv0 = t * FA_BKV;
-        if (t + 1 < ntiles) gload(kv0 + FA_BKV);
+        if (t + 1 < ntiles) FA_GLOAD(kv0 + FA_BKV);
         const float* Ks = smem + cur * (2 * FA_BKV * FA_LD);
         const float* Vs = Ks + FA_BKV * FA_LD;
 
-        f32x16 sT[2];
+        f32x16 s0, s1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sT[0][r] = sT[1][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
         const float* kp = Ks + l31 * FA_LD + 4 * hh;
+        // K fragments are read one 8-wide k-group ahead of the MFMAs that use them
+        f32x4 kf0[8], kf1[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            kf0[q] = *reinterpret_cast<const f32x4*>(kp + 8 * q);
+            kf1[q] = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * q);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + 8 * q);
-            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[j], qf[q][j], sT[0], 0, 0, 0);
-                sT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[j], qf[q][j], sT[1], 0, 0, 0);
+            if (q + 2 < 8) {
+                kf0[q + 2] = *reinterpret_cast<const f32x4*>(kp + 8 * (q + 2));
+                kf1[q + 2] = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * (q + 2));
             }
+            const f32x4 k0 = kf0[q], k1 = kf1[q], qq = qf[q];
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[0], qq[0], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[0], qq[0], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[1], qq[1], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[1], qq[1], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[2], qq[2], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[2], qq[2], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[3], qq[3], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[3], qq[3], s1, 0, 0, 0);
         }
         if (kv0 + FA_BKV > S) {  // ragged last tile: keys >= S get probability 0
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= S) sT[kt][r] = -INFINITY;
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
         }
-        float mx = sT[0][0];
+        float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sT[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[1][r]);
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float ps = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sT[kt][r] = __expf(sT[kt][r] - m_new);
-                ps += sT[kt][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __expf(s0[r] - m_new);
+            s1[r] = __expf(s1[r] - m_new);
+            ps += s0[r] + s1[r];
+        }
         l_run = l_run * alpha + ps;  // per-lane partial (16 of the query's 32 keys per tile); halves merged at the end
         m_run = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            oT[0][r] *= alpha;
-            oT[1][r] *= alpha;
+            o0[r] *= alpha;
+            o1[r] *= alpha;
         }
+        const float* vbase = Vs + 4 * hh * FA_LD + l31;
+        // P.V: V values are fetched four keys ahead of the MFMAs that consume them (counted LDS waits, no per-MFMA stall)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int g = 0; g < 4; ++g) {
+            float va[4], vb[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* vp = Vs + (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * FA_LD + l31;
-                oT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], sT[kt][r], oT[0], 0, 0, 0);
-                oT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], sT[kt][r], oT[1], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                va[i] = vbase[(8 * g + i) * FA_LD];
+                vb[i] = vbase[(8 * g + i) * FA_LD + 32];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], s0[4 * g + i], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[i], s0[4 * g + i], o1, 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) lstore(cur ^ 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = vbase[(32 + 8 * g + i) * FA_LD];
+                vb[i] = vbase[(32 + 8 * g + i) * FA_LD + 32];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], s1[4 * g + i], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[i], s1[4 * g + i], o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) FA_LSTORE(cur ^ 1);
         __syncthreads();
     }
+#undef FA_GLOAD
+#undef FA_LSTORE
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
     if (qrow < S) {
         float* op = ctx + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 o;
-                o.x = oT[tt][4 * g + 0] * inv;
-                o.y = oT[tt][4 * g + 1] * inv;
-                o.z = oT[tt][4 * g + 2] * inv;
-                o.w = oT[tt][4 * g + 3] * inv;
-                *reinterpret_cast<float4*>(op + 32 * tt + 8 * g) = o;
-            }
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(op + 8 * g) =
+                make_float4(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                make_float4(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
     }
 }
 
