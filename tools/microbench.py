@@ -17,17 +17,26 @@ ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def timeit(fn, n_rot, iters=5):
+    """us per launch.  The n_rot launches are captured into one graph (as the decode step is) and replayed, so the
+    number includes the in-graph kernel boundary but no host launch cost."""
     for i in range(n_rot):
         fn(i)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for i in range(n_rot):
+                fn(i)
+    g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        for i in range(n_rot):
-            fn(i)
+        g.replay()
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e3 / (iters * n_rot)  # us per launch
+    return a.elapsed_time(b) * 1e3 / (iters * n_rot)
 
 
 def bench_dec_attn(B=8, H=16, S=1500, L=24):
@@ -41,7 +50,7 @@ def bench_dec_attn(B=8, H=16, S=1500, L=24):
     for ns in (1, 2, 3, 4, 6, 8):
         part = torch.empty(B, H, ns, 68, device="cuda")
         us = timeit(lambda i: lib.wt_dbg_decode_attention(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), B, H, S, S, ns, ST()), L)
-        print(f"dec_attn S={S} n_split={ns}: {us:7.2f} us  {mb / us * 1e-3 * 1e3:7.1f} GB/s")
+        print(f"dec_attn S={S} n_split={ns}: {us:7.2f} us  {mb / us * 1e-3 * 1e3:7.1f} TB/s")
     for length in (32, 224, 447):
         for ns in (1, 2, 4):
             part = torch.empty(B, H, ns, 68, device="cuda")
@@ -50,14 +59,25 @@ def bench_dec_attn(B=8, H=16, S=1500, L=24):
 
 
 def bench_skinny(B=8, L=24):
-    for (N, K, xmode) in ((1024, 1024, 0), (1024, 1024, 1), (3072, 1024, 1), (4096, 1024, 1), (1024, 4096, 0), (51864, 1024, 1)):
+    for (N, K, xmode) in ((1024, 1024, 0), (1024, 1024, 2), (1024, 1024, 1), (3072, 1024, 1), (4096, 1024, 1), (1024, 4096, 0), (51864, 1024, 1)):
         n_rot = L if N < 50000 else 4
         W = torch.randn(n_rot, N, K, device="cuda") * 0.02
         X = torch.randn(B, K, device="cuda")
         g, be, bias = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(N, device="cuda")
         Y = torch.empty(B, N, device="cuda")
         us = timeit(lambda i: lib.wt_dbg_skinny(P(X), P(g), P(be), P(W[i]), P(bias), None, P(Y), B, N, K, xmode, 0, 1.0, ST()), n_rot)
-        print(f"skinny N={N} K={K} xmode={xmode}: {us:7.2f} us  {N * K * 4 / us * 1e-3:7.1f} GB/s")
+        print(f"skinny N={N} K={K} xmode={xmode}: {us:7.2f} us  {N * K * 4 / us * 1e-3:7.1f} TB/s")
+
+
+def bench_skinny_floor(B=8):
+    """Fixed cost of a decode-step GEMV launch: tiny problem, and the real shapes with cache-resident weights."""
+    for (N, K, xmode, n_rot) in ((64, 256, 0, 1), (1024, 1024, 0, 1), (1024, 1024, 1, 1), (4096, 1024, 1, 1), (1024, 4096, 0, 1), (4096, 1024, 1, 24)):
+        W = torch.randn(n_rot, N, K, device="cuda") * 0.02
+        X = torch.randn(B, K, device="cuda")
+        g, be, bias = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(N, device="cuda")
+        Y = torch.empty(B, N, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_skinny(P(X), P(g), P(be), P(W[i % n_rot]), P(bias), None, P(Y), B, N, K, xmode, 0, 1.0, ST()), 24)
+        print(f"skinny N={N} K={K} xmode={xmode} rotating {n_rot}: {us:7.2f} us")
 
 
 def bench_gemm(M=12000):
@@ -77,9 +97,25 @@ def bench_enc_attn(B=8, S=1500, H=16):
     print(f"enc_attn B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_dec_attn_resident(B=8, H=16, S=1500):
+    """Same cross-attention launch with the K/V of ONE layer re-read every launch: 98 MB stays in the 256 MB
+    Infinity Cache, i.e. the rate a prefetch-ahead design could reach."""
+    for L in (1, 2, 4):
+        d = 64 * H
+        q = torch.randn(B, d, device="cuda") * 0.3
+        k = torch.randn(L, B, H, S, 64, device="cuda")
+        v = torch.randn(L, B, H, S, 64, device="cuda")
+        out = torch.empty(B, d, device="cuda")
+        cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+        part = torch.empty(B, H, 2, 68, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_decode_attention(P(q), P(k[i % L]), P(v[i % L]), P(part), P(cnt), P(out), B, H, S, S, 2, ST()), 24)
+        print(f"dec_attn S={S} n_split=2, {L} rotating layer(s) ({L * 98} MB working set): {us:7.2f} us")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["dec_attn", "skinny", "gemm", "enc_attn"])
     a = ap.parse_args()
     for name in a.what:
         globals()["bench_" + name]()
+

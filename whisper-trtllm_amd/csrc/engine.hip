@@ -418,8 +418,8 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
 }
 
 static int pick_splits(int B, int H, int len) {
-    // enough (utterance, head, split) blocks for ~2 waves of the 256 CUs, at least ~48 keys per split
-    int n = (512 + B * H - 1) / (B * H);
+    // about one (utterance, head, split) block per CU (256), at least ~48 keys per split
+    int n = (256 + B * H - 1) / (B * H);
     if (n < 1) n = 1;
     while (n > 1 && len / n < 48) --n;
     if (n > 16) n = 16;
@@ -556,8 +556,10 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     if (!same) e->graph_valid = false;
     e->B = B; e->max_length = p->max_length; e->begin_index = p->begin_index; e->eos = p->eos_token_id;
     e->pad = p->pad_token_id; e->force_eos_step = p->force_eos_step; e->trace = p->logits_trace;
+    // measured (tools/microbench.py, medium.en B=8): self attention is fastest unsplit at every length <= 448;
+    // cross attention (1500 keys) with ~one block per CU
+    e->nsplit_self = 1;
     e->nsplit_cross = pick_splits(B, e->H, e->S);
-    e->nsplit_self = pick_splits(B, e->H, e->T / 2);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
     rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, s);
     if (rc) return rc;
@@ -784,7 +786,7 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     StepIO io;
     io.ids = data; io.ids_ld = 1; io.self_k = nsk; io.self_v = nsv; io.self_cap = cache_len + 1;
     io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1;
-    io.nsplit_self = pick_splits(1, e->H, cache_len + 1); io.nsplit_cross = pick_splits(1, e->H, S);
+    io.nsplit_self = 1; io.nsplit_cross = pick_splits(1, e->H, S);
     e->begun = false;  // the resident greedy state is clobbered by this call
     return enqueue_step(e, io, s);
 }
