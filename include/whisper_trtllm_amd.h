@@ -142,6 +142,10 @@ typedef struct {
 /* enable/disable event timing of the dominant decode kernel (cross-attention) and the encoder GEMM */
 int wt_engine_set_profiling(wt_engine* e, int enabled);
 int wt_engine_get_timer(wt_engine* e, const char* which, wt_kernel_timer* out);
+/* average launch time (us) of the dominant decode kernel, cross-attention, over the engine's resident caches:
+ * the L per-layer launches are captured into a hipGraph (as the decode step runs them), replayed `iters` times
+ * between two hipEvents on the launch stream.  Needs a decode in flight (wt_decoder_begin).  Synchronises. */
+int wt_decoder_time_cross_attention(wt_engine* dec, int iters, float* avg_us, void* stream);
 
 const char* wt_last_error(void);
 int wt_abi_version(void);

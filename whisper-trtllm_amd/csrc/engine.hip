@@ -792,6 +792,53 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
 }
 
 // ------------------------------------------------------------------------------------------------- profiling
+// Average launch time of the dominant decode kernel (cross-attention) measured the way the decode step runs it:
+// the L per-layer launches over the engine's resident cross-KV caches are captured into a hipGraph, the graph is
+// replayed `iters` times between two hipEvents recorded on the launch stream, and the elapsed time is divided by
+// iters * L.  (Events cannot bracket single kernels inside the step graph; an eager pass adds dispatch gaps.)
+extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* avg_us, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER || !avg_us || iters < 1) return fail(WT_E_INVALID, "wt_decoder_time_cross_attention: bad arguments");
+    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_time_cross_attention needs a decode in flight (wt_decoder_begin)");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipEventRecord(e->ev_in, s));
+    HIPCHK(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < e->L && le == hipSuccess; ++i) {
+        DecAttnParams a;
+        memset(&a, 0, sizeof a);
+        a.q = e->dq; a.kcache = e->cross_k + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
+        a.vcache = e->cross_v + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
+        a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = e->B; a.H = e->H; a.s_cap = e->S;
+        a.n_split = e->nsplit_cross; a.fixed_len = e->S;
+        le = launch_dec_attn(a, e->own_stream);
+    }
+    hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
+    if (le != hipSuccess || ce != hipSuccess) return fail(WT_E_HIP, "capturing the cross-attention timing graph failed");
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipGraphLaunch(ge, e->own_stream));  // warm-up replay
+    HIPCHK(hipEventRecord(a, e->own_stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(ge, e->own_stream));
+    HIPCHK(hipEventRecord(b, e->own_stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *avg_us = ms * 1e3f / ((float)iters * e->L);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
+    HIPCHK(hipStreamWaitEvent(s, e->ev_out, 0));
+    return WT_OK;
+}
+
 extern "C" int wt_engine_set_profiling(wt_engine* e, int enabled) {
     if (!e) return fail(WT_E_INVALID, "null engine");
     e->profiling = enabled != 0;

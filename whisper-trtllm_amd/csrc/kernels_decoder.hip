@@ -104,37 +104,51 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
     if (nsplit == 1 && !(p.xmode == XMODE_PLAIN && p.x_direct)) {
         // every wave of the block needs the same NB whole rows: stage them once per block through LDS.
         // Wave w loads (and LayerNorm-s) rows w, w+4, ...; after the barrier each wave pulls all rows to registers.
-        for (int b = wave; b < NB; b += 4) {
-            float4 xv[4];
+        // gamma/beta are requested together with the rows (not after the statistics) to keep them off the critical path
+        float4 g[4], be[4];
+        if (p.xmode == XMODE_LAYERNORM) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {  // gamma = beta = 0 outside the row, so padding lanes stay 0
+                g[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                be[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float4 xv[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int b = wave + 4 * j;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                xv[v] = (kok[v] && b < p.B) ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + 4 * lane + 256 * v)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[j][v] = (kok[v] && b < p.B && b < NB) ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + 4 * lane + 256 * v)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int b = wave + 4 * j;
+            if (b >= NB) break;
             if (p.xmode == XMODE_LAYERNORM) {
                 float sum = 0.f;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) sum += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
+                for (int v = 0; v < 4; ++v) sum += (xv[j][v].x + xv[j][v].y) + (xv[j][v].z + xv[j][v].w);
                 const float mean = wave_allreduce_sum_d(sum) / p.K;
                 float q = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
                     if (kok[v]) {
-                        float a = xv[v].x - mean, c = xv[v].y - mean, e = xv[v].z - mean, f = xv[v].w - mean;
+                        float a = xv[j][v].x - mean, c = xv[j][v].y - mean, e = xv[j][v].z - mean, f = xv[j][v].w - mean;
                         q += (a * a + c * c) + (e * e + f * f);
                     }
                 const float rstd = rsqrtf(wave_allreduce_sum_d(q) / p.K + 1e-5f);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {  // gamma = beta = 0 outside the row, so padding lanes stay 0
-                    const float4 g = kok[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 be = kok[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    xv[v].x = (xv[v].x - mean) * rstd * g.x + be.x;
-                    xv[v].y = (xv[v].y - mean) * rstd * g.y + be.y;
-                    xv[v].z = (xv[v].z - mean) * rstd * g.z + be.z;
-                    xv[v].w = (xv[v].w - mean) * rstd * g.w + be.w;
+                for (int v = 0; v < 4; ++v) {
+                    xv[j][v].x = (xv[j][v].x - mean) * rstd * g[v].x + be[v].x;
+                    xv[j][v].y = (xv[j][v].y - mean) * rstd * g[v].y + be[v].y;
+                    xv[j][v].z = (xv[j][v].z - mean) * rstd * g[v].z + be[v].z;
+                    xv[j][v].w = (xv[j][v].w - mean) * rstd * g[v].w + be[v].w;
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&xs[b][4 * lane + 256 * v]) = xv[v];
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&xs[b][4 * lane + 256 * v]) = xv[j][v];
         }
         __syncthreads();
 #pragma unroll

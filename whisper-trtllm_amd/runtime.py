@@ -241,6 +241,15 @@ class WhisperDecoderEngine:
     def set_profiling(self, enabled: bool):
         _lib.check(self.session._lib.wt_engine_set_profiling(self.session.handle, int(enabled)), "wt_engine_set_profiling")
 
+    def time_cross_attention(self, iters: int = 20) -> float:
+        """Average launch time (us) of the cross-attention kernel, graph-replayed over the resident caches."""
+        import torch
+        us = ctypes.c_float()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_time_cross_attention(self.session.handle, iters, ctypes.byref(us),
+                                                                      ctypes.c_void_p(stream)), "wt_decoder_time_cross_attention")
+        return float(us.value)
+
     def timer(self, which: str):
         t = _lib.KernelTimer()
         _lib.check(self.session._lib.wt_engine_get_timer(self.session.handle, which.encode(), ctypes.byref(t)), "wt_engine_get_timer")
