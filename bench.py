@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=6)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs round-robin")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,12 +65,17 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: there is no CPU execution path for the engine")
+    if args.share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     cfg = w.synthetic.get_config(args.model)
     cfg["max_length"] = args.max_length
@@ -98,10 +105,7 @@ def main():
             ids = one_pass(**kw)
         torch.cuda.synchronize()
         el = time.perf_counter() - t
-        if dist is not None:
-            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+        el = w.sharding.max_over_ranks(el, dist)
         barrier()
         return el, ids
 
@@ -148,9 +152,16 @@ def main():
         # dominant kernel by time: decoder cross-attention (streams the utterances' resident K/V once per step)
         bytes_cross = B * H * S * 64 * 4 * 2          # cross-KV bytes/step/utt / L, x B utterances per launch
         avg_cross = us_cross * 1e-6
+        traffic = None   # HBM bytes per launch from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_dominant_kernel.json")))
+            if B == 8 and args.model == "whisper-medium.en":
+                traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         ach = bytes_cross / avg_cross / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, S=1500)", "achieved": round(ach, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "bytes_per_launch": bytes_cross, "avg_launch_us": round(avg_cross * 1e6, 2), "launches": 40 * L,
                            "timing": "hipGraph replay of the L per-layer launches over the resident caches, hipEvents on the launch stream"}
         F_, C = cfg["encoder_ffn_dim"], cfg["num_mel_bins"]
