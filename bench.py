@@ -123,7 +123,7 @@ def main():
     value_n32 = 30.0 * B * world * max(1, args.steps) / el32
 
     out = {
-        "metric": "audio-sec/s, whisper-medium.en fp32 greedy", "value": round(value, 2), "unit": "audio-seconds/second",
+        "metric": f"audio-sec/s, {args.model} fp32 greedy", "value": round(value, 2), "unit": "audio-seconds/second",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} fp32 greedy, batch {B} per GPU x 30 s / 80x3000 synthetic log-mel, "
