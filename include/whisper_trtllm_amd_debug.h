@@ -15,6 +15,9 @@ extern "C" {
 /* C[M][N] = act(A[M][K(lda)] W[N][K]^T + bias) (+ resid); act: 0 none, 1 erf-GELU */
 int wt_dbg_gemm(const float* A, int lda, const float* W, const float* bias, const float* resid, float* C, int M, int N,
                 int K, int act, void* stream);
+/* fp16 operands (A [M][K(lda)], W [N][K] as IEEE half), fp32 accumulate; C is half when out_half else float */
+int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N, int K,
+                    int act, int out_half, void* stream);
 int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream);
 /* qkv [B*S][3*H*64] -> ctx [B*S][H*64], softmax(QK^T/8)V per head */
 int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, void* stream);

@@ -51,6 +51,39 @@ def test_gemm(lib, M, N, K, act, use_res):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
+    (128, 128, 64, 0, 0, False), (200, 136, 240, 1, 1, False), (1500, 384, 384, 0, 0, True), (97, 1000, 1536, 1, 1, False),
+    (3000, 128, 240, 1, 1, False), (33, 51, 8, 0, 0, False), (1024, 3072, 1024, 0, 0, True)])
+def test_gemm_f16(lib, M, N, K, act, out_half, use_res):
+    A, W, b = _rand(M, K, seed=1).half(), _rand(N, K, seed=2, scale=K ** -0.5).half(), _rand(N, seed=3)
+    R = _rand(M, N, seed=4) if use_res else None
+    ref = F.linear(A.double(), W.double(), b.double())   # fp16 inputs are exact in fp64: only accumulation differs
+    if act:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    C = (R.cuda().clone() if use_res else torch.empty(M, N, device="cuda"))
+    if out_half:
+        C = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    assert lib.wt_dbg_gemm_f16(P(Ad), K, P(Wd), P(bd), P(C) if use_res else None, P(C), M, N, K, act, out_half, _stream()) == 0
+    torch.cuda.synchronize()
+    err = (C.cpu().double() - ref).abs().max().item()
+    tol = (2e-3 if out_half else 2e-5) * max(1.0, ref.abs().max().item())
+    assert err < tol, err
+
+
+def test_gemm_f16_identity_asymmetric(lib):
+    n = 160
+    A = torch.eye(n).half()
+    W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 / 8.0).half()
+    C = torch.empty(n, n, device="cuda")
+    Ad, Wd = A.cuda(), W.cuda()
+    assert lib.wt_dbg_gemm_f16(P(Ad), n, P(Wd), None, None, P(C), n, n, n, 0, 0, _stream()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(C.cpu().numpy(), W.float().t().numpy())
+
+
 def test_gemm_identity_asymmetric(lib):
     """A = I with an asymmetric W catches a transposed C/D fragment map (cdna guide §3)."""
     n = 160

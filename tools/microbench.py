@@ -90,6 +90,16 @@ def bench_gemm(M=12000):
         print(f"gemm M={M} N={N} K={K} act={act}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_gemm_f16(M=12000):
+    for (N, K, act, oh) in ((3072, 1024, 0, 0), (1024, 1024, 0, 0), (4096, 1024, 1, 1), (1024, 4096, 0, 0), (1024, 3072, 1, 0)):
+        A = torch.randn(M, K, device="cuda").half()
+        W = (torch.randn(4, N, K, device="cuda") * 0.03).half()
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda", dtype=torch.float16 if oh else torch.float32)
+        us = timeit(lambda i: lib.wt_dbg_gemm_f16(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, ST()), 4, iters=3)
+        print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+
+
 def bench_enc_attn(B=8, S=1500, H=16):
     qkv = torch.randn(B * S, 3 * 64 * H, device="cuda")
     ctx = torch.empty(B * S, 64 * H, device="cuda")

@@ -20,7 +20,7 @@ EXPORTS = [
     "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention",
     "wt_last_error", "wt_abi_version",
 ]
-DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_skinny", "wt_dbg_decode_attention"]
+DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_f16", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_skinny", "wt_dbg_decode_attention"]
 
 
 class TensorDesc(Structure):
@@ -92,6 +92,7 @@ def load():
     lib.wt_decoder_time_cross_attention.argtypes = [c_void_p, c_int, POINTER(c_float), c_void_p]
     P, I, F = c_void_p, c_int, c_float
     lib.wt_dbg_gemm.argtypes = [P, I, P, P, P, P, I, I, I, I, P]
+    lib.wt_dbg_gemm_f16.argtypes = [P, I, P, P, P, P, I, I, I, I, I, P]
     lib.wt_dbg_layernorm.argtypes = [P, P, P, P, I, I, P]
     lib.wt_dbg_encoder_attention.argtypes = [P, P, I, I, I, P]
     lib.wt_dbg_skinny.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, F, P]

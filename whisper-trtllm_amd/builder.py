@@ -48,16 +48,17 @@ class Builder:
         if model is None:
             logger.error("build_engine: no model was traced inside net_guard(network)")
             return None
-        if builder_config.precision != "float32":
-            logger.error("build_engine: only float32 engines are implemented on this path "
-                         "(float16 encoder is planned; see DESIGN.md)")
+        half = builder_config.precision == "float16"
+        if half and not isinstance(model, WhisperEncoder):
+            logger.error("build_engine: float16 is implemented for the encoder engine only (fp16 encoder + fp32 decoder, "
+                         "BASELINE config 4); build the decoder with --engine_precision float32")
             return None
         params = dict(network.named_parameters()) or dict(model.named_parameters())
         f32 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float32)
         val = lambda name: f32(params[name].value)
         try:
             if isinstance(model, WhisperEncoder):
-                blob = self._pack_encoder(model, val, f32)
+                blob = self._pack_encoder(model, val, f32, half)
             elif isinstance(model, WhisperDecoder):
                 blob = self._pack_decoder(model, val, f32)
             else:
@@ -74,7 +75,7 @@ class Builder:
         assert one == 1 and k == 3
         return np.ascontiguousarray(w4[:, :, 0, :].transpose(0, 2, 1).reshape(d, 3 * c))  # [co][k*C + ci]
 
-    def _pack_encoder(self, m: WhisperEncoder, val, f32) -> bytes:
+    def _pack_encoder(self, m: WhisperEncoder, val, f32, half: bool = False) -> bytes:
         t = {
             "conv1.weight": self._conv_as_gemm(val("conv1.weight")), "conv1.bias": val("conv1.bias"),
             "conv2.weight": self._conv_as_gemm(val("conv2.weight")), "conv2.bias": val("conv2.bias"),
@@ -89,7 +90,14 @@ class Builder:
         t["layer_norm.weight"], t["layer_norm.bias"] = val("layer_norm.weight"), val("layer_norm.bias")
         cfg = dict(d_model=m.d_model, n_heads=m.encoder_attention_heads, n_layers=len(m.layers),
                    ffn_dim=m.encoder_ffn_dim, n_mels=m.num_mel_bins, max_source_positions=m.max_source_positions)
-        return engine_pack.pack(engine_pack.KIND_ENCODER, _dtypes.float32.code, cfg, t)
+        if half:  # GEMM operands in fp16; biases, LayerNorm parameters and embed_positions stay fp32
+            if m.num_mel_bins % 8 or m.d_model % 8:
+                raise ValueError("float16 encoder needs num_mel_bins and d_model to be multiples of 8")
+            for name in list(t):
+                if name.endswith(".weight") and t[name].ndim == 2:
+                    t[name] = t[name].astype(np.float16)
+        prec = _dtypes.float16.code if half else _dtypes.float32.code
+        return engine_pack.pack(engine_pack.KIND_ENCODER, prec, cfg, t)
 
     def _pack_decoder(self, m: WhisperDecoder, val, f32) -> bytes:
         d = m.d_model

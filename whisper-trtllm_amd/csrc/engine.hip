@@ -32,6 +32,7 @@ static int fail(int code, const char* fmt, ...) {
 
 struct DevTensor {
     float* ptr = nullptr;
+    int dtype = WT_F32;
     int ndim = 0;
     int64_t shape[4] = {0, 0, 0, 0};
 };
@@ -64,6 +65,7 @@ struct wt_engine {
     int enc_cap = 0;
     char* enc_ws = nullptr;
     float *melT = nullptr, *c1 = nullptr, *hbuf = nullptr, *xbuf = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
+    void *melT_h = nullptr, *c1_h = nullptr, *x_h = nullptr, *ctx_h = nullptr, *ffn_h = nullptr;  // fp16 engines
     // decoder
     std::vector<DecLayerW> dec_layers;
     const float *tok_emb = nullptr, *pos_emb = nullptr, *proj_w = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
@@ -166,8 +168,8 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         return fail(WT_E_INVALID, "engine blob is truncated or corrupt (header says %llu bytes, got %zu)",
                     (unsigned long long)hd.total_bytes, nbytes);
     if (hd.kind != WT_KIND_ENCODER && hd.kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "unknown engine kind %u", hd.kind);
-    if (hd.precision != WT_F32)
-        return fail(WT_E_UNSUPPORTED, "engine precision %u: only float32 engines are implemented", hd.precision);
+    if (hd.precision != WT_F32 && !(hd.precision == WT_F16 && hd.kind == WT_KIND_ENCODER))
+        return fail(WT_E_UNSUPPORTED, "engine precision %u: float32, or float16 for the encoder engine only", hd.precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(WT_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -175,6 +177,7 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
 
     wt_engine* e = new wt_engine();
     e->kind = (int)hd.kind;
+    e->precision = (int)hd.precision;
     e->device = device;
     e->d = hd.cfg[CFG_D_MODEL]; e->H = hd.cfg[CFG_HEADS]; e->L = hd.cfg[CFG_LAYERS]; e->F = hd.cfg[CFG_FFN];
     e->C = hd.cfg[CFG_MELS]; e->S = hd.cfg[CFG_SRC_POS]; e->T = hd.cfg[CFG_TGT_POS]; e->V = hd.cfg[CFG_VOCAB];
@@ -209,7 +212,7 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         BlobTensor bt;
         memcpy(&bt, tab + i, sizeof bt);
         bt.name[sizeof(bt.name) - 1] = 0;
-        if (bt.offset < hd.data_off || bt.offset + bt.nbytes > nbytes || (bt.offset & 15) || bt.dtype != WT_F32 || bt.ndim > 4) {
+        if (bt.offset < hd.data_off || bt.offset + bt.nbytes > nbytes || (bt.offset & 15) || (bt.dtype != WT_F32 && bt.dtype != WT_F16) || bt.ndim > 4) {
             int rc = fail(WT_E_INVALID, "tensor '%s' has a bad table entry", bt.name);
             wt_engine_close(e);
             return rc;
@@ -217,9 +220,10 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         DevTensor t;
         t.ptr = (float*)(e->weights_base + (bt.offset - hd.data_off));
         t.ndim = (int)bt.ndim;
+        t.dtype = (int)bt.dtype;
         int64_t n = 1;
         for (uint32_t k = 0; k < bt.ndim; ++k) { t.shape[k] = bt.shape[k]; n *= bt.shape[k]; }
-        if ((uint64_t)n * 4 != bt.nbytes) {
+        if ((uint64_t)n * (bt.dtype == WT_F16 ? 2 : 4) != bt.nbytes) {
             int rc = fail(WT_E_INVALID, "tensor '%s': shape and byte count disagree", bt.name);
             wt_engine_close(e);
             return rc;
@@ -235,6 +239,13 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         bool ok = it->second.ndim == (int)shape.size();
         for (int64_t s : shape) { ok = ok && it->second.shape[k] == s; ++k; }
         if (!ok && !g_err[0]) fail(WT_E_INVALID, "tensor '%s' has the wrong shape for this config", name.c_str());
+        // fp16 engines carry their GEMM operands (2-D *.weight) as fp16, everything else as fp32
+        const bool is_gemm_w = shape.size() == 2 && name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
+        const int want = (e->precision == WT_F16 && is_gemm_w) ? WT_F16 : WT_F32;
+        if (ok && it->second.dtype != want) {
+            ok = false;
+            if (!g_err[0]) fail(WT_E_INVALID, "tensor '%s' has the wrong element type for this engine precision", name.c_str());
+        }
         return ok ? it->second.ptr : nullptr;
     };
     const int64_t d = e->d, F = e->F;
@@ -307,11 +318,14 @@ static int enc_reserve(wt_engine* e, int B) {
     const size_t o_melT = take((size_t)B * (Fr + 2) * e->C + 4 * e->C);
     const size_t o_c1 = take((size_t)B * (Fr + 2) * d + 4 * d);
     const size_t o_h = take(M * d), o_x = take(M * d), o_qkv = take(M * 3 * d), o_ctx = take(M * d), o_ffn = take(M * e->F);
+    // fp16 engines reuse the fp32-sized regions for their half-precision activations (half the bytes)
     hipError_t he = hipMalloc((void**)&e->enc_ws, off);
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for encoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     e->melT = (float*)(e->enc_ws + o_melT); e->c1 = (float*)(e->enc_ws + o_c1); e->hbuf = (float*)(e->enc_ws + o_h);
     e->xbuf = (float*)(e->enc_ws + o_x); e->qkv = (float*)(e->enc_ws + o_qkv); e->ctx = (float*)(e->enc_ws + o_ctx);
     e->ffn = (float*)(e->enc_ws + o_ffn);
+    e->melT_h = e->melT; e->c1_h = e->c1; e->x_h = e->xbuf; e->ffn_h = e->ffn;
+    e->ctx_h = (char*)e->ffn + M * e->F * 2;  // second half of the ffn region (M*F*2 bytes >= M*d*2)
     // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
     HIPCHK(hipMemset(e->melT, 0, ((size_t)B * (Fr + 2) * e->C + 4 * e->C) * 4));
     HIPCHK(hipMemset(e->c1, 0, ((size_t)B * (Fr + 2) * d + 4 * d) * 4));
@@ -333,6 +347,57 @@ static int timed_gemm(wt_engine* e, const GemmParams& p, hipStream_t s) {
     return WT_OK;
 }
 
+// fp16 encoder: fp16 GEMM operands, fp32 accumulation / residual stream / LayerNorm statistics / attention.
+static int encoder_forward_f16(wt_engine* e, const float* mel, int B, float* out, hipStream_t s) {
+    const int S = e->S, Fr = 2 * S, d = e->d, C = e->C, M = B * S;
+    int rc;
+    auto hgemm = [&](const GemmParams& q, bool out_half) {
+        hipEvent_t a, b;
+        timer_begin(e, e->t_gemm, s, &a, &b);
+        hipError_t le = launch_gemm_f16(q, out_half, s);
+        timer_end(e, e->t_gemm, s, a, b);
+        return le == hipSuccess ? WT_OK : fail(WT_E_HIP, "fp16 GEMM launch failed: %s", hipGetErrorString(le));
+    };
+    LAUNCH(launch_mel_transpose_h(mel, e->melT_h, B, C, Fr, s));
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = (const float*)e->melT_h; g.lda = C; g.a_rows_per_batch = Fr; g.a_batch_stride = (long long)(Fr + 2) * C;
+    g.W = e->conv1_w; g.bias = e->conv1_b; g.M = B * Fr; g.N = d; g.K = 3 * C; g.act = 1;
+    g.C = (float*)((char*)e->c1_h + (size_t)d * 2); g.ldc = d; g.c_rows_per_batch = Fr; g.c_batch_stride = (long long)(Fr + 2) * d;
+    if ((rc = hgemm(g, true))) return rc;
+    memset(&g, 0, sizeof g);
+    g.A = (const float*)e->c1_h; g.lda = 2 * d; g.a_rows_per_batch = S; g.a_batch_stride = (long long)(Fr + 2) * d;
+    g.W = e->conv2_w; g.bias = e->conv2_b; g.M = M; g.N = d; g.K = 3 * d; g.act = 1; g.pos = e->enc_pos;
+    g.C = e->hbuf; g.ldc = d; g.c_rows_per_batch = S; g.c_batch_stride = (long long)S * d;
+    if ((rc = hgemm(g, false))) return rc;
+    auto dense = [&](const void* A, int K, const float* Wt, const float* bias, int N, void* Cout, int act, const float* resid,
+                     bool out_half) {
+        GemmParams q;
+        memset(&q, 0, sizeof q);
+        q.A = (const float*)A; q.lda = K; q.a_rows_per_batch = M; q.W = Wt; q.bias = bias; q.M = M; q.N = N; q.K = K; q.act = act;
+        q.C = (float*)Cout; q.ldc = N; q.c_rows_per_batch = M; q.resid = resid;
+        return hgemm(q, out_half);
+    };
+    for (int i = 0; i < e->L; ++i) {
+        const EncLayerW& l = e->enc_layers[i];
+        LAUNCH(launch_layernorm_h(e->hbuf, l.ln1_w, l.ln1_b, e->x_h, M, d, s));
+        if ((rc = dense(e->x_h, d, l.qkv_w, l.qkv_b, 3 * d, e->qkv, 0, nullptr, false))) return rc;
+        {
+            hipEvent_t a, b;
+            timer_begin(e, e->t_enc_attn, s, &a, &b);
+            LAUNCH(launch_encoder_attention(e->qkv, e->ctx, B, S, e->H, s));
+            timer_end(e, e->t_enc_attn, s, a, b);
+        }
+        LAUNCH(launch_cast_h(e->ctx, e->ctx_h, (size_t)M * d, s));
+        if ((rc = dense(e->ctx_h, d, l.o_w, l.o_b, d, e->hbuf, 0, e->hbuf, false))) return rc;
+        LAUNCH(launch_layernorm_h(e->hbuf, l.ln2_w, l.ln2_b, e->x_h, M, d, s));
+        if ((rc = dense(e->x_h, d, l.fc1_w, l.fc1_b, e->F, e->ffn_h, 1, nullptr, true))) return rc;
+        if ((rc = dense(e->ffn_h, e->F, l.fc2_w, l.fc2_b, d, e->hbuf, 0, e->hbuf, false))) return rc;
+    }
+    LAUNCH(launch_layernorm(e->hbuf, e->enc_ln_w, e->enc_ln_b, out, M, d, s));
+    return WT_OK;
+}
+
 extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* out, void* stream) {
     if (!e || e->kind != WT_KIND_ENCODER) return fail(WT_E_INVALID, "wt_encoder_forward: not an encoder engine");
     if (!mel || !out || B < 1) return fail(WT_E_INVALID, "wt_encoder_forward: bad arguments (batch %d)", B);
@@ -341,6 +406,7 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int S = e->S, Fr = 2 * S, d = e->d, C = e->C, M = B * S;
+    if (e->precision == WT_F16) return encoder_forward_f16(e, mel, B, out, s);
     LAUNCH(launch_mel_transpose(mel, e->melT, B, C, Fr, s));
     GemmParams g;
     memset(&g, 0, sizeof g);

@@ -1,0 +1,242 @@
+// fp16-encoder kernels (engine precision "float16", BASELINE config 4: fp16 encoder + fp32 decoder).
+// Weights and GEMM inputs are fp16, every accumulation is fp32 on v_mfma_f32_16x16x32_f16, the residual stream,
+// LayerNorm statistics, softmax and the encoder output stay fp32 (the reference forces fp32 scores even in fp16
+// builds, model.py:292-295, and marks hidden_states float32, model.py:109).
+#include "wt_common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace wt {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_erf_h(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------------ fp32 -> fp16 helpers
+// mel [B][C][F] fp32 -> melT [B][F+2][C] fp16 (row = time+1; rows 0 / F+1 zero) : conv1 as implicit GEMM, K = 3C
+__global__ __launch_bounds__(256) void mel_transpose_h_kernel(const float* __restrict__ mel, __half* __restrict__ melT, int C, int F) {
+    __shared__ float tile[128][65];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        int c = i >> 6, tl = i & 63, t = t0 + tl;
+        tile[c][tl] = t < F ? mel[((size_t)b * C + c) * F + t] : 0.f;
+    }
+    __syncthreads();
+    __half* dst = melT + (size_t)b * (F + 2) * C;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        int tl = i / C, c = i - tl * C, t = t0 + tl;
+        if (t < F) dst[(size_t)(t + 1) * C + c] = __float2half(tile[c][tl]);
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < C; i += 256) {
+            dst[i] = __float2half(0.f);
+            dst[(size_t)(F + 1) * C + i] = __float2half(0.f);
+        }
+}
+hipError_t launch_mel_transpose_h(const float* mel, void* melT, int B, int n_mels, int frames, hipStream_t s) {
+    if (n_mels > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mel_transpose_h_kernel, dim3((frames + 63) / 64, B), dim3(256), 0, s, mel, (__half*)melT, n_mels, frames);
+    return hipGetLastError();
+}
+
+// LayerNorm fp32 in -> fp16 out (statistics in fp32), one wave per row
+__global__ __launch_bounds__(256) void layernorm_h_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, __half* __restrict__ y, int rows, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    const int n4 = d >> 2;
+    float4 v[5];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < n4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        if (lane + 64 * i < n4) {
+            float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + bb * bb) + (cc * cc + dd * dd);
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / d + 1e-5f);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    __half2* yr = reinterpret_cast<__half2*>(y + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        if (c < n4) {
+            float4 g = w4[c], be = b4[c];
+            yr[2 * c] = __floats2half2_rn((v[i].x - mean) * rstd * g.x + be.x, (v[i].y - mean) * rstd * g.y + be.y);
+            yr[2 * c + 1] = __floats2half2_rn((v[i].z - mean) * rstd * g.z + be.z, (v[i].w - mean) * rstd * g.w + be.w);
+        }
+    }
+}
+hipError_t launch_layernorm_h(const float* x, const float* w, const float* b, void* y, int rows, int d, hipStream_t s) {
+    if (d > 1280 || (d & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_h_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, (__half*)y, rows, d);
+    return hipGetLastError();
+}
+
+// fp32 -> fp16 elementwise (attention context for the out-projection)
+__global__ __launch_bounds__(256) void cast_h_kernel(const float4* __restrict__ x, __half2* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x[i];
+        y[2 * i] = __floats2half2_rn(v.x, v.y);
+        y[2 * i + 1] = __floats2half2_rn(v.z, v.w);
+    }
+}
+hipError_t launch_cast_h(const float* x, void* y, size_t n, hipStream_t s) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cast_h_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const float4*>(x), (__half2*)y, n >> 2);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ fp16 MFMA GEMM
+// C[m][n] = epi(sum_k A[m][k] W[n][k] + bias[n]); A, W fp16, accumulate fp32, C fp16 or fp32.
+// 128x128x64 block tile, 4 waves (2x2), each wave 4x4 tiles of v_mfma_f32_16x16x32_f16.  Register-staged,
+// double-buffered LDS with 160-byte rows (128 B of data + 32 B pad): for the 16x16x32 fragment read
+// (lane -> row l&15, 16-byte k-chunk l>>4) every ds_read_b128 lane group then covers 16 distinct 16-byte slots.
+constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64, HLD_ = 80;  // HLD in halfs
+constexpr int HGEMM_SMEM = 2 * 2 * HBM_ * HLD_ * 2;          // 81,920 B
+
+template <bool OUT_HALF>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __half* smem = reinterpret_cast<__half*>(smem_raw);
+    const __half* A = reinterpret_cast<const __half*>(p.A);
+    const __half* W = reinterpret_cast<const __half*>(p.W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * HBM_, n0 = bx * HBN_;
+
+    // staging: 128 rows x 8 sixteen-byte chunks per matrix; thread -> chunk c8, rows r0 + 32 i
+    const int c8 = tid & 7, r0 = tid >> 3;
+    auto arow = [&](int i) -> const __half* {
+        const int m = min(m0 + r0 + 32 * i, p.M - 1);
+        const int bb = m / p.a_rows_per_batch;
+        return A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + c8 * 8;
+    };
+    auto wrow = [&](int i) -> const __half* { return W + (long long)min(n0 + r0 + 32 * i, p.N - 1) * p.K + c8 * 8; };
+    const __half *ap0 = arow(0), *ap1 = arow(1), *ap2 = arow(2), *ap3 = arow(3);
+    const __half *wp0 = wrow(0), *wp1 = wrow(1), *wp2 = wrow(2), *wp3 = wrow(3);
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+#define HG_LOAD(kt_)                                                                         \
+    do {                                                                                     \
+        const bool ok_ = (kt_) * HBK_ + c8 * 8 < p.K;                                        \
+        ra0 = ok_ ? *reinterpret_cast<const uint4*>(ap0 + (kt_) * HBK_) : z4;            \
+        ra1 = ok_ ? *reinterpret_cast<const uint4*>(ap1 + (kt_) * HBK_) : z4;            \
+        ra2 = ok_ ? *reinterpret_cast<const uint4*>(ap2 + (kt_) * HBK_) : z4;            \
+        ra3 = ok_ ? *reinterpret_cast<const uint4*>(ap3 + (kt_) * HBK_) : z4;            \
+        rw0 = ok_ ? *reinterpret_cast<const uint4*>(wp0 + (kt_) * HBK_) : z4;            \
+        rw1 = ok_ ? *reinterpret_cast<const uint4*>(wp1 + (kt_) * HBK_) : z4;            \
+        rw2 = ok_ ? *reinterpret_cast<const uint4*>(wp2 + (kt_) * HBK_) : z4;            \
+        rw3 = ok_ ? *reinterpret_cast<const uint4*>(wp3 + (kt_) * HBK_) : z4;            \
+    } while (0)
+#define HG_STORE(buf_)                                                                       \
+    do {                                                                                     \
+        __half* As_ = smem + (buf_) * (2 * HBM_ * HLD_) + r0 * HLD_ + c8 * 8;                \
+        __half* Ws_ = As_ + HBM_ * HLD_;                                                     \
+        *reinterpret_cast<uint4*>(As_) = ra0; *reinterpret_cast<uint4*>(As_ + 32 * HLD_) = ra1;           \
+        *reinterpret_cast<uint4*>(As_ + 64 * HLD_) = ra2; *reinterpret_cast<uint4*>(As_ + 96 * HLD_) = ra3; \
+        *reinterpret_cast<uint4*>(Ws_) = rw0; *reinterpret_cast<uint4*>(Ws_ + 32 * HLD_) = rw1;           \
+        *reinterpret_cast<uint4*>(Ws_ + 64 * HLD_) = rw2; *reinterpret_cast<uint4*>(Ws_ + 96 * HLD_) = rw3; \
+    } while (0)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + HBK_ - 1) / HBK_;
+    HG_LOAD(0);
+    HG_STORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) HG_LOAD(kt + 1);
+        const __half* As = smem + cur * (2 * HBM_ * HLD_) + (wr * 64 + l15) * HLD_ + 8 * kq;
+        const __half* Ws = smem + cur * (2 * HBM_ * HLD_) + HBM_ * HLD_ + (wc * 64 + l15) * HLD_ + 8 * kq;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            h8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const h8*>(As + i * 16 * HLD_ + 32 * s);
+                bf[i] = *reinterpret_cast<const h8*>(Ws + i * 16 * HLD_ + 32 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) HG_STORE(cur ^ 1);
+        __syncthreads();
+    }
+#undef HG_LOAD
+#undef HG_STORE
+    // epilogue: 16x16 C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        const int n = n0 + wc * 64 + tj * 16 + l15;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 64 + ti * 16 + kq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[ti][tj][r] + bv;
+                if (p.act) v = gelu_erf_h(v);
+                const int cb = m / p.c_rows_per_batch, cr = m - cb * p.c_rows_per_batch;
+                if (p.pos) v += p.pos[(long long)cr * p.N + n];
+                const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
+                if (p.resid) v += p.resid[off];
+                if (OUT_HALF) reinterpret_cast<__half*>(p.C)[off] = __float2half(v);
+                else p.C[off] = v;
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HGEMM_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HGEMM_SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
+    if (out_half) hipLaunchKernelGGL(gemm_f16_kernel<true>, dim3(nbx * nby), dim3(256), HGEMM_SMEM, s, p);
+    else hipLaunchKernelGGL(gemm_f16_kernel<false>, dim3(nbx * nby), dim3(256), HGEMM_SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace wt

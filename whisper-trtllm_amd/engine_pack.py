@@ -28,13 +28,15 @@ def pack(kind: int, precision_code: int, cfg: Dict[str, int], tensors: Dict[str,
     data_off = (table_off + _TEN.size * len(names) + _ALIGN - 1) // _ALIGN * _ALIGN
     entries, chunks, off = [], [], data_off
     for name in names:
-        a = np.ascontiguousarray(tensors[name], dtype=np.float32)
+        a = np.ascontiguousarray(tensors[name])
+        if a.dtype not in (np.float32, np.float16):
+            a = a.astype(np.float32)
         if a.ndim > 4:
             raise ValueError(f"{name}: rank {a.ndim} > 4")
         if len(name.encode()) >= 96:
             raise ValueError(f"tensor name too long: {name}")
         shape = list(a.shape) + [0] * (4 - a.ndim)
-        entries.append(_TEN.pack(name.encode(), 0, a.ndim, *shape, off, a.nbytes))
+        entries.append(_TEN.pack(name.encode(), 0 if a.dtype == np.float32 else 1, a.ndim, *shape, off, a.nbytes))
         pad = (-a.nbytes) % _ALIGN
         chunks.append(a.tobytes() + b"\0" * pad)
         off += a.nbytes + pad
@@ -58,7 +60,8 @@ def unpack(blob: bytes) -> Tuple[dict, Dict[str, np.ndarray]]:
     info = {"kind": kind, "precision": precision, **dict(zip(CFG_KEYS, cfg_vals))}
     tensors = {}
     for i in range(n):
-        name, _dt, ndim, s0, s1, s2, s3, off, nb = _TEN.unpack_from(blob, table_off + i * _TEN.size)
+        name, dt, ndim, s0, s1, s2, s3, off, nb = _TEN.unpack_from(blob, table_off + i * _TEN.size)
         shape = (s0, s1, s2, s3)[:ndim]
-        tensors[name.rstrip(b"\0").decode()] = np.frombuffer(blob, np.float32, nb // 4, off).reshape(shape)
+        npdt = np.float32 if dt == 0 else np.float16
+        tensors[name.rstrip(b"\0").decode()] = np.frombuffer(blob, npdt, nb // np.dtype(npdt).itemsize, off).reshape(shape)
     return info, tensors
