@@ -88,3 +88,17 @@ def test_fp16_encoder_engine(wt, case):
     assert wt.Builder().build_engine is not None
     with pytest.raises(AssertionError):
         wt.convert.build_decoder_engine(cfg, weights, precision="float16")   # decoder stays fp32
+
+
+def test_batches_larger_than_eight_are_chunked(wt):
+    """B = 11 > 8 (the per-call engine batch): rows are independent, so ids must equal per-utterance decoding."""
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 31)
+    enc, dec = _engines(wt, cfg, weights)
+    mel = torch.from_numpy(wt.synthetic.make_mel(cfg, index=40, batch=11)).cuda()
+    hidden = enc(mel)
+    ids = dec.generate(hidden).cpu().numpy()
+    assert ids.shape[0] == 11
+    for b in (0, 7, 8, 10):
+        one = dec.generate(hidden[b:b + 1]).cpu().numpy()[0]
+        np.testing.assert_array_equal(ids[b, :len(one)], one)

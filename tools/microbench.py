@@ -59,7 +59,7 @@ def bench_dec_attn(B=8, H=16, S=1500, L=24):
 
 
 def bench_skinny(B=8, L=24):
-    for (N, K, xmode) in ((1024, 1024, 0), (1024, 1024, 2), (1024, 1024, 1), (3072, 1024, 1), (4096, 1024, 1), (1024, 4096, 0), (51864, 1024, 1)):
+    for (N, K, xmode) in ((1024, 1024, 0), (1024, 1024, 4), (1024, 1024, 1), (1024, 1024, 5), (3072, 1024, 5), (4096, 1024, 5), (1024, 4096, 4), (51864, 1024, 5), (3072, 1024, 1), (4096, 1024, 1), (1024, 4096, 0), (51864, 1024, 1)):
         n_rot = L if N < 50000 else 4
         W = torch.randn(n_rot, N, K, device="cuda") * 0.02
         X = torch.randn(B, K, device="cuda")

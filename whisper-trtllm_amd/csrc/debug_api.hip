@@ -28,7 +28,7 @@ extern "C" int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_
     SkinnyParams k;
     memset(&k, 0, sizeof k);
     k.X = X; k.ln_w = ln_w; k.ln_b = ln_b; k.W = W; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B; k.N = N; k.K = K;
-    k.xmode = xmode & 1; k.x_direct = (xmode >> 1) & 1; k.act = act; k.q_scale = scale; k.ymode = YMODE_PLAIN;
+    k.xmode = xmode & 1; k.x_direct = (xmode >> 1) & 1; k.w_nt = (xmode >> 2) & 1; k.act = act; k.q_scale = scale; k.ymode = YMODE_PLAIN;
     return rc_of(launch_skinny(k, (hipStream_t)stream));
 }
 extern "C" int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt,

@@ -516,7 +516,7 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         memset(&k, 0, sizeof k);
         k.X = e->dh; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
         k.Y = e->dq; k.kcache = sk; k.vcache = sv; k.st = e->st; k.B = B; k.N = 3 * d; k.K = d; k.ymode = YMODE_QKV_APPEND;
-        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f;
+        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         memset(&a, 0, sizeof a);
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
@@ -524,12 +524,12 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         LAUNCH(launch_dec_attn(a, s));
         memset(&k, 0, sizeof k);
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = e->dh;
-        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f;
+        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         // --- cross attention over the encoder memory (model.py:261-272): K/V already resident
         memset(&k, 0, sizeof k);
         k.X = e->dh; k.ln_w = l.ln2_w; k.ln_b = l.ln2_b; k.xmode = XMODE_LAYERNORM; k.W = l.cq_w; k.bias = l.cq_b;
-        k.Y = e->dq; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 0.125f;
+        k.Y = e->dq; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 0.125f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         memset(&a, 0, sizeof a);
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
@@ -542,22 +542,22 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         }
         memset(&k, 0, sizeof k);
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = e->dh;
-        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f;
+        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         // --- FFN (model.py:363-367)
         memset(&k, 0, sizeof k);
         k.X = e->dh; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
-        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f;
+        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         memset(&k, 0, sizeof k);
         k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = e->dh; k.Y = e->dh; k.st = e->st;
-        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f;
+        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
     }
     // final LN + vocabulary projection (model.py:455-457; logits are the engine's 'hidden_states' output)
     memset(&k, 0, sizeof k);
     k.X = e->dh; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
-    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f;
+    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
     {
         hipEvent_t ta, tb;
         timer_begin(e, e->t_skinny, s, &ta, &tb);

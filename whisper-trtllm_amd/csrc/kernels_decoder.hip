@@ -68,7 +68,7 @@ hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, co
 // reduced across the wave by a halving butterfly (v_permlane32_swap, v_permlane16_swap, then DPP row
 // rotations), leaving each (row, batch) total in one lane, which applies the epilogue.
 // When K > 1024 the 4 waves of a block split K (nsplit = 2 or 4) and combine through LDS.
-template <int NB>
+template <int NB, bool W_NT>
 __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
                                                              const int rows_per_group) {
     __shared__ float comb[2][4][2 * NB];
@@ -93,8 +93,15 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
         for (int r = 0; r < 2; ++r) {
             const float* wp = p.W + (size_t)min(row + r, p.N - 1) * p.K + ks0 + 4 * lane;
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                wbuf[buf][r][v] = kok[v] ? *reinterpret_cast<const float4*>(wp + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = 0; v < 4; ++v) {
+                if (W_NT) {  // weights are read exactly once per step: non-temporal (streaming) loads
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    f4v t = f4v{0.f, 0.f, 0.f, 0.f};
+                    if (kok[v]) t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(wp + 256 * v));
+                    wbuf[buf][r][v] = make_float4(t[0], t[1], t[2], t[3]);
+                } else
+                    wbuf[buf][r][v] = kok[v] ? *reinterpret_cast<const float4*>(wp + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     // the first two W rows are requested before the activation prologue so their HBM latency hides under it
@@ -271,12 +278,15 @@ hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
     if (rows_per_group < 2) rows_per_group = 2;
     const int groups = (p.N + rows_per_group - 1) / rows_per_group;
     const int grid = (groups + G - 1) / G;
-    if (p.B <= 2)
-        hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);
-    else if (p.B <= 4)
-        hipLaunchKernelGGL(skinny_gemm_kernel<4>, dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);
-    else
-        hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);
+#define WT_SKINNY_LAUNCH(NB_)                                                                                          \
+    do {                                                                                                               \
+        if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB_, true>), dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);  \
+        else hipLaunchKernelGGL((skinny_gemm_kernel<NB_, false>), dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);        \
+    } while (0)
+    if (p.B <= 2) WT_SKINNY_LAUNCH(2);
+    else if (p.B <= 4) WT_SKINNY_LAUNCH(4);
+    else WT_SKINNY_LAUNCH(8);
+#undef WT_SKINNY_LAUNCH
     return hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ struct SkinnyParams {
     const DecState* st;
     int B, N, K;
     int xmode;             // XMODE_*
+    int w_nt;              // stream W with non-temporal loads
     int x_direct;          // PLAIN only: every wave loads its activations straight from L2 (no LDS staging)
     int act;               // 0 none, 1 GELU
     int ymode;

@@ -229,7 +229,17 @@ class WhisperDecoderEngine:
     def generate(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None, chunk: int = 16):
         """== greedy_search(...) of run.py:171-227 for a batch; returns int32 ids [B, len] on the GPU."""
         if encoder_hidden.shape[0] > self.max_batch:
-            raise ValueError(f"at most {self.max_batch} utterances per call; shard larger batches")
+            # larger batches (e.g. BASELINE config 4, B=16) run as consecutive engine batches of <= 8 utterances;
+            # rows are independent, so the result is the concatenation (shorter groups are right-padded with pad_token_id)
+            import torch
+            if logits_trace is not None:
+                raise ValueError(f"logits_trace supports at most {self.max_batch} utterances per call")
+            parts = [self.generate(encoder_hidden[i:i + self.max_batch], max_length, force_eos_step, None, chunk)
+                     for i in range(0, encoder_hidden.shape[0], self.max_batch)]
+            width = max(p.shape[1] for p in parts)
+            pad = self.config["pad_token_id"]
+            parts = [torch.nn.functional.pad(p, (0, width - p.shape[1]), value=pad) for p in parts]
+            return torch.cat(parts, dim=0)
         self.begin(encoder_hidden, max_length, force_eos_step, logits_trace)
         cur, done = 1, False
         ml = self._p.max_length
