@@ -147,6 +147,19 @@ int wt_engine_get_timer(wt_engine* e, const char* which, wt_kernel_timer* out);
  * between two hipEvents on the launch stream.  Needs a decode in flight (wt_decoder_begin).  Synchronises. */
 int wt_decoder_time_cross_attention(wt_engine* dec, int iters, float* avg_us, void* stream);
 
+/* ---- log-mel front-end: replaces the CPU numpy STFT inside the reference's timed loop,
+ * `hf_processor(sample["array"], ...)` run.py:267 == WhisperFeatureExtractor._np_extract_fbank_features
+ * (transformers/models/whisper/feature_extraction_whisper.py:94-111).  The host passes the constant tables:
+ * dft f32 [ndft][n_fft] (rows 0..n_bins-1 = cos, rows ndft/2 .. ndft/2+n_bins-1 = -sin, other rows 0), the Hann
+ * window [n_fft] and the mel filter bank [n_mels][npw] (columns >= n_bins zero). */
+typedef struct wt_logmel wt_logmel;
+int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int n_frames, const float* dft, int ndft, const float* window,
+                     const float* filters, int npw, wt_logmel** out);
+void wt_logmel_destroy(wt_logmel* h);
+/* audio f32 [batch][n_in] on the device (n_in samples each; shorter than 30 s = zero-padded, longer = trimmed)
+ * -> mel_out f32 [batch][n_mels][n_frames].  Asynchronous on `stream`. */
+int wt_logmel_forward(wt_logmel* h, const float* audio, int batch, int n_in, float* mel_out, void* stream);
+
 const char* wt_last_error(void);
 int wt_abi_version(void);
 

@@ -247,3 +247,54 @@ def greedy_search(W: Weights, cfg: dict, enc_out: torch.Tensor, max_length: Opti
 def transcribe(W: Weights, cfg: dict, mel: torch.Tensor, **kw):
     """Encoder + greedy decode == `hf_model.generate(mel)` in run.py:305-306."""
     return greedy_search(W, cfg, encoder_forward(W, cfg, mel), **kw)
+
+
+# ----------------------------------------------------------------------------- log-mel front-end (SURVEY §8(f) rank 1)
+def _hertz_to_mel_slaney(freq):
+    """HF audio_utils.py:25-57 (mel_scale='slaney')."""
+    freq = np.asarray(freq, dtype=np.float64)
+    mels = 3.0 * freq / 200.0
+    logstep = 27.0 / np.log(6.4)
+    with np.errstate(divide="ignore"):
+        return np.where(freq >= 1000.0, 15.0 + np.log(np.maximum(freq, 1e-300) / 1000.0) * logstep, mels)
+
+
+def _mel_to_hertz_slaney(mels):
+    """HF audio_utils.py:59-90."""
+    mels = np.asarray(mels, dtype=np.float64)
+    logstep = np.log(6.4) / 27.0
+    return np.where(mels >= 15.0, 1000.0 * np.exp(logstep * (mels - 15.0)), 200.0 * mels / 3.0)
+
+
+def whisper_mel_filters(n_freq: int = 201, n_mels: int = 80, sr: int = 16000) -> np.ndarray:
+    """HF audio_utils.mel_filter_bank(201, 80, 0, 8000, 16000, norm='slaney', mel_scale='slaney') :115-190 -> [n_freq, n_mels]."""
+    fft_freqs = np.linspace(0, sr // 2, n_freq)
+    mel_freqs = np.linspace(_hertz_to_mel_slaney(0.0), _hertz_to_mel_slaney(8000.0), n_mels + 2)
+    filter_freqs = _mel_to_hertz_slaney(mel_freqs)
+    filter_diff = np.diff(filter_freqs)
+    slopes = np.expand_dims(filter_freqs, 0) - np.expand_dims(fft_freqs, 1)
+    down = -slopes[:, :-2] / filter_diff[:-1]
+    up = slopes[:, 2:] / filter_diff[1:]
+    fb = np.maximum(np.zeros(1), np.minimum(down, up))
+    return fb * np.expand_dims(2.0 / (filter_freqs[2:n_mels + 2] - filter_freqs[:n_mels]), 0)
+
+
+def log_mel_spectrogram(waveform: np.ndarray) -> np.ndarray:
+    """HF WhisperFeatureExtractor: pad/trim to 30 s (feature_extraction_whisper.py:229-237), then
+    _np_extract_fbank_features :94-111 over audio_utils.spectrogram :267-452 (float64 frames, rfft stored as
+    complex64, |.|^2, mel, max(1e-10), log10, float32), drop last frame, clamp to max-8, (x+4)/4.
+    waveform float32 [n] at 16 kHz -> float32 [80, 3000]."""
+    n_fft, hop, n_samples = 400, 160, 480000
+    x = np.zeros(n_samples, dtype=np.float32)
+    w = np.asarray(waveform, dtype=np.float32)[:n_samples]
+    x[:len(w)] = w
+    x = np.pad(x, [(n_fft // 2, n_fft // 2)], mode="reflect").astype(np.float64)
+    window = np.hanning(n_fft + 1)[:-1].astype(np.float64)
+    num_frames = int(1 + np.floor((x.size - n_fft) / hop))
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(num_frames)[:, None]
+    spec = np.fft.rfft(x[idx] * window[None, :], axis=-1).astype(np.complex64)
+    power = np.abs(spec, dtype=np.float64) ** 2.0
+    mel = np.maximum(1e-10, np.dot(whisper_mel_filters().T, power.T))
+    log_spec = np.asarray(np.log10(mel), np.float32)[:, :-1]
+    log_spec = np.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0

@@ -1,0 +1,89 @@
+"""Log-mel front-end.  CPU: the oracle restatement and the product's constant tables against the
+golden vectors recorded from the reference's WhisperFeatureExtractor.  GPU: the HIP front-end against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ref
+from conftest import GOLDEN_DIR
+
+
+def synthetic_waveform(seed: int, seconds: float) -> np.ndarray:
+    """Identical to tests/golden/make_golden_frontend.py::synthetic_waveform."""
+    rng = np.random.default_rng(seed)
+    n = int(16000 * seconds)
+    t = np.arange(n) / 16000.0
+    chirp = np.sin(2 * np.pi * (200.0 + 900.0 * t / max(seconds, 1e-3)) * t)
+    env = 0.5 + 0.5 * np.sin(2 * np.pi * 0.7 * t + seed)
+    return (0.6 * env * chirp + 0.05 * rng.standard_normal(n)).astype(np.float32)
+
+
+CASES = ["full30s", "short5s", "long34s", "silence_tail"]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(GOLDEN_DIR, "frontend.npz")))
+
+
+def test_mel_filter_bank_matches_reference(gold):
+    import whisper_trtllm_amd as wt
+    for fb in (cpu_ref.whisper_mel_filters(), wt.audio.mel_filter_bank()):
+        assert fb.shape == (201, 80)
+        np.testing.assert_allclose(fb[::7, ::3], gold["mel_filters_sub"], atol=1e-12)
+        assert abs(fb.sum() - float(gold["mel_filters_sum"])) < 1e-9
+    dft, ndft = wt.audio.dft_tables()
+    frame = np.random.default_rng(0).standard_normal(400)
+    spec = np.fft.rfft(frame)
+    got = dft.astype(np.float64) @ frame
+    np.testing.assert_allclose(got[:201], spec.real, atol=2e-4)
+    np.testing.assert_allclose(got[ndft // 2:ndft // 2 + 201], spec.imag, atol=2e-4)
+    assert not got[201:ndft // 2].any() and not got[ndft // 2 + 201:].any()
+    np.testing.assert_allclose(wt.audio.hann_window(), np.hanning(401)[:-1])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_frontend_matches_reference(gold, case):
+    wav = synthetic_waveform(int(gold[f"{case}_seed"]), float(gold[f"{case}_seconds"]))
+    feats = cpu_ref.log_mel_spectrogram(wav)
+    assert feats.shape == (80, 3000) and feats.dtype == np.float32
+    np.testing.assert_allclose(feats[::5, ::37], gold[f"{case}_sub"], atol=1e-5)
+    np.testing.assert_allclose(feats[:, :4], gold[f"{case}_frames_head"], atol=1e-5)
+    np.testing.assert_allclose(feats[:, -4:], gold[f"{case}_frames_tail"], atol=1e-5)
+    assert abs(float(feats.max()) - float(gold[f"{case}_max"])) < 1e-5 and abs(float(feats.mean()) - float(gold[f"{case}_mean"])) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_frontend_matches_oracle_and_reference(gold, case):
+    """fp32 MFMA DFT vs the reference's float64 rfft: features agree to 2e-3 abs (clamped range is 2.0 wide);
+    the bulk (99%) agrees to 2e-4.  Spectral-leakage-floor bins carry the fp32 rounding of a 400-term DFT."""
+    import whisper_trtllm_amd as wt
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    wav = synthetic_waveform(int(gold[f"{case}_seed"]), float(gold[f"{case}_seconds"]))
+    fe = wt.audio.LogMelFrontend()
+    got = fe(torch.from_numpy(wav).cuda()[None])[0].cpu().numpy()
+    ref = cpu_ref.log_mel_spectrogram(wav)
+    assert got.shape == (80, 3000) and np.isfinite(got).all()
+    err = np.abs(got - ref)
+    assert err.max() < 2e-3, err.max()
+    assert np.quantile(err, 0.99) < 2e-4, np.quantile(err, 0.99)
+    np.testing.assert_allclose(got[::5, ::37], gold[f"{case}_sub"], atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_frontend_batched_and_feeds_the_encoder():
+    import whisper_trtllm_amd as wt
+    wavs = np.stack([synthetic_waveform(10 + i, 30.0) for i in range(3)])
+    fe = wt.audio.LogMelFrontend()
+    mel = fe(torch.from_numpy(wavs).cuda())
+    assert tuple(mel.shape) == (3, 80, 3000)
+    for i in range(3):
+        np.testing.assert_allclose(mel[i].cpu().numpy(), cpu_ref.log_mel_spectrogram(wavs[i]), atol=2e-3)
+    cfg = wt.synthetic.get_config("toy")
+    enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, wt.synthetic.make_weights(cfg, 2)))
+    hidden = enc(mel)
+    assert tuple(hidden.shape) == (3, 1500, cfg["d_model"]) and torch.isfinite(hidden).all()

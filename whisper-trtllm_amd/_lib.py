@@ -18,7 +18,7 @@ EXPORTS = [
     "wt_engine_open", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
     "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_read_ids",
     "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention",
-    "wt_last_error", "wt_abi_version",
+    "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
 DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_f16", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_skinny", "wt_dbg_decode_attention"]
 
@@ -89,6 +89,10 @@ def load():
     lib.wt_decoder_greedy.argtypes = [c_void_p, c_void_p, c_int, POINTER(GreedyParams), c_void_p, POINTER(c_int), c_void_p]
     lib.wt_engine_set_profiling.argtypes = [c_void_p, c_int]
     lib.wt_engine_get_timer.argtypes = [c_void_p, c_char_p, POINTER(KernelTimer)]
+    lib.wt_logmel_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p)]
+    lib.wt_logmel_destroy.argtypes = [c_void_p]
+    lib.wt_logmel_destroy.restype = None
+    lib.wt_logmel_forward.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.wt_decoder_time_cross_attention.argtypes = [c_void_p, c_int, POINTER(c_float), c_void_p]
     P, I, F = c_void_p, c_int, c_float
     lib.wt_dbg_gemm.argtypes = [P, I, P, P, P, P, I, I, I, I, P]

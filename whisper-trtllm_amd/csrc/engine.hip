@@ -23,6 +23,13 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int wt_set_error(int code, const char* fmt, ...) {  // shared with frontend.hip
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
 #define HIPCHK(expr)                                                                                      \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \
