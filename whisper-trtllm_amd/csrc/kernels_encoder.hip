@@ -7,6 +7,8 @@
 // modeling_whisper.py:569-593, :632-641, :992-1011 (erf GELU, q scaled before QK^T).
 #include "wt_common.h"
 
+#include <stdlib.h>
+
 namespace wt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -105,15 +107,21 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, floa
 
 // ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
 // 128x128 block tile, 4 waves in a 2x2 grid, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32 (exact fp32,
-// 64 FLOP/clk/SIMD).  A and W tiles are staged global -> registers -> LDS (rows padded by 4 floats so the
+// 64 FLOP/clk/SIMD), K-step 16 (32 selectable).  A and W tiles are staged global -> registers -> LDS (rows padded by 4 floats so the
 // ds_read_b128 fragment reads are bank-conflict free), double-buffered, one barrier per K-step.
 // Fragment trick: one 32x32x2 MFMA takes k = {k0, k1} from lane halves 0/1.  Each lane reads a float4
 // A[row][8q+4h .. +3] and issues 4 MFMAs with element j, so lane half h covers k = 8q+4h+j; A and W use the
 // same k assignment, so the sum over k is complete and no repacking is needed.
-constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBK + 4;
-constexpr int GEMM_SMEM = 2 * 2 * GBM * GLD * (int)sizeof(float);  // 73,728 B
+constexpr int GBM = 128, GBN = 128;
+template <int GBK>
+constexpr int gemm_smem_bytes() { return 2 * 2 * GBM * (GBK + 4) * (int)sizeof(float); }  // 73,728 B at BK=32, 40,960 B at BK=16
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
+template <int GBK>
+__global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const GemmParams p) {
+    constexpr int GLD = GBK + 4;
+    constexpr int NC4 = GBK / 4;           // float4 chunks per staged row
+    constexpr int RPP = 256 / NC4;         // rows covered per staging pass
+    constexpr int NPASS = GBM / RPP;       // passes per matrix
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -134,24 +142,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
     const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
     const int m0 = by * GBM, n0 = bx * GBN;
 
-    // staging map: 128 rows x 8 float4; thread -> column c4, rows r0 + 32*i
-    const int c4 = tid & 7, r0 = tid >> 3;
-    const float* aptr[4];
-    const float* wptr[4];
+    // staging map: 128 rows x NC4 float4; thread -> column c4, rows r0 + RPP*i
+    const int c4 = tid % NC4, r0 = tid / NC4;
+    const float* aptr[NPASS];
+    const float* wptr[NPASS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = min(m0 + r0 + 32 * i, p.M - 1);
+    for (int i = 0; i < NPASS; ++i) {
+        int m = min(m0 + r0 + RPP * i, p.M - 1);
         int bb = m / p.a_rows_per_batch;
         aptr[i] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + c4 * 4;
-        int n = min(n0 + r0 + 32 * i, p.N - 1);
+        int n = min(n0 + r0 + RPP * i, p.N - 1);
         wptr[i] = p.W + (long long)n * p.K + c4 * 4;
     }
-    float4 ra[4], rw[4];
+    float4 ra[NPASS], rw[NPASS];
     auto gload = [&](int kt) {
         const int k = kt * GBK + c4 * 4;
         const bool ok = k < p.K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPASS; ++i) {
             ra[i] = ok ? *reinterpret_cast<const float4*>(aptr[i] + kt * GBK) : make_float4(0.f, 0.f, 0.f, 0.f);
             rw[i] = ok ? *reinterpret_cast<const float4*>(wptr[i] + kt * GBK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -160,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
         float* As = smem + buf * (2 * GBM * GLD);
         float* Ws = As + GBM * GLD;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(As + (r0 + 32 * i) * GLD + c4 * 4) = ra[i];
-            *reinterpret_cast<float4*>(Ws + (r0 + 32 * i) * GLD + c4 * 4) = rw[i];
+        for (int i = 0; i < NPASS; ++i) {
+            *reinterpret_cast<float4*>(As + (r0 + RPP * i) * GLD + c4 * 4) = ra[i];
+            *reinterpret_cast<float4*>(Ws + (r0 + RPP * i) * GLD + c4 * 4) = rw[i];
         }
     };
 
@@ -242,14 +250,26 @@ hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3)) return hipErrorInvalidValue;
     static bool attr_set = false;
+    static int force_bk = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<32>());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<16>());
         if (e != hipSuccess) return e;
+        const char* ev = getenv("WT_GEMM_BK");
+        force_bk = ev ? atoi(ev) : 0;
         attr_set = true;
     }
     const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(nbx * nby), dim3(256), GEMM_SMEM, s, p);
+    // measured (tools/microbench.py gemm, M=12000): BK=16 (41 KB of LDS, 128 VGPRs -> 3-4 resident blocks per CU, smaller idle
+    // tail in the last round of tiles) beats BK=32 (2 blocks per CU) on every encoder shape: 97-120 vs 77-108 TFLOP/s
+    const int tiles = nbx * nby;
+    int bk = 16;
+    if (force_bk == 16 || force_bk == 32) bk = force_bk;
+    if (bk == 16) hipLaunchKernelGGL(gemm_f32_kernel<16>, dim3(tiles), dim3(256), gemm_smem_bytes<16>(), s, p);
+    else hipLaunchKernelGGL(gemm_f32_kernel<32>, dim3(tiles), dim3(256), gemm_smem_bytes<32>(), s, p);
     return hipGetLastError();
 }
 
