@@ -5,13 +5,25 @@
 #include "wt_common.h"
 
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 namespace wt {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float gelu_erf_h(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside the fp16 path's tolerance): one rcp + one exp + 6 FMAs
+// instead of erff()'s ~40 instructions -- the GELU epilogue of a K=1024 fp16 tile otherwise costs as much as its main loop
+__device__ __forceinline__ float gelu_erf_h(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = 1.0f - poly * t * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 // ------------------------------------------------------------------------------------------------ fp32 -> fp16 helpers
 // mel [B][C][F] fp32 -> melT [B][F+2][C] fp16 (row = time+1; rows 0 / F+1 zero) : conv1 as implicit GEMM, K = 3C
@@ -106,11 +118,18 @@ hipError_t launch_cast_h(const float* x, void* y, size_t n, hipStream_t s) {
 // 128x128x64 block tile, 4 waves (2x2), each wave 4x4 tiles of v_mfma_f32_16x16x32_f16.  Register-staged,
 // double-buffered LDS with 160-byte rows (128 B of data + 32 B pad): for the 16x16x32 fragment read
 // (lane -> row l&15, 16-byte k-chunk l>>4) every ds_read_b128 lane group then covers 16 distinct 16-byte slots.
-constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64, HLD_ = 80;  // HLD in halfs
-constexpr int HGEMM_SMEM = 2 * 2 * HBM_ * HLD_ * 2;          // 81,920 B
+constexpr int HBM_ = 128, HBN_ = 128;
+// row stride in halfs: 128 B of data + 32 B pad at BK=64, 64 B + 32 B at BK=32 (both keep every ds_read_b128 lane group on
+// 16 distinct 16-byte slots for the 16x16x32 fragment map)
+template <int HBK_> constexpr int hgemm_ld() { return HBK_ == 64 ? 80 : 48; }
+template <int HBK_> constexpr int hgemm_smem() { return 2 * 2 * HBM_ * hgemm_ld<HBK_>() * 2; }  // 81,920 B / 49,152 B
 
-template <bool OUT_HALF>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
+template <bool OUT_HALF, int HBK_>
+__global__ __launch_bounds__(256, HBK_ == 64 ? 2 : 3) void gemm_f16_kernel(const GemmParams p) {
+    constexpr int HLD_ = hgemm_ld<HBK_>();
+    constexpr int NC8 = HBK_ / 8;        // 16-byte chunks per staged row
+    constexpr int RPP = 256 / NC8;       // rows per staging pass (32 or 64)
+    constexpr int NPASS = HBM_ / RPP;    // 4 or 2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __half* smem = reinterpret_cast<__half*>(smem_raw);
     const __half* A = reinterpret_cast<const __half*>(p.A);
@@ -131,38 +150,42 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
     const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
     const int m0 = by * HBM_, n0 = bx * HBN_;
 
-    // staging: 128 rows x 8 sixteen-byte chunks per matrix; thread -> chunk c8, rows r0 + 32 i
-    const int c8 = tid & 7, r0 = tid >> 3;
+    // staging: 128 rows x NC8 sixteen-byte chunks per matrix; thread -> chunk c8, rows r0 + RPP i
+    const int c8 = tid % NC8, r0 = tid / NC8;
     auto arow = [&](int i) -> const __half* {
-        const int m = min(m0 + r0 + 32 * i, p.M - 1);
+        const int m = min(m0 + r0 + RPP * i, p.M - 1);
         const int bb = m / p.a_rows_per_batch;
         return A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + c8 * 8;
     };
-    auto wrow = [&](int i) -> const __half* { return W + (long long)min(n0 + r0 + 32 * i, p.N - 1) * p.K + c8 * 8; };
+    auto wrow = [&](int i) -> const __half* { return W + (long long)min(n0 + r0 + RPP * i, p.N - 1) * p.K + c8 * 8; };
     const __half *ap0 = arow(0), *ap1 = arow(1), *ap2 = arow(2), *ap3 = arow(3);
     const __half *wp0 = wrow(0), *wp1 = wrow(1), *wp2 = wrow(2), *wp3 = wrow(3);
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    uint4 ra0, ra1, ra2 = make_uint4(0, 0, 0, 0), ra3 = ra2, rw0, rw1, rw2 = ra2, rw3 = ra2;
     const uint4 z4 = make_uint4(0, 0, 0, 0);
 #define HG_LOAD(kt_)                                                                         \
     do {                                                                                     \
         const bool ok_ = (kt_) * HBK_ + c8 * 8 < p.K;                                        \
         ra0 = ok_ ? *reinterpret_cast<const uint4*>(ap0 + (kt_) * HBK_) : z4;            \
         ra1 = ok_ ? *reinterpret_cast<const uint4*>(ap1 + (kt_) * HBK_) : z4;            \
-        ra2 = ok_ ? *reinterpret_cast<const uint4*>(ap2 + (kt_) * HBK_) : z4;            \
-        ra3 = ok_ ? *reinterpret_cast<const uint4*>(ap3 + (kt_) * HBK_) : z4;            \
         rw0 = ok_ ? *reinterpret_cast<const uint4*>(wp0 + (kt_) * HBK_) : z4;            \
         rw1 = ok_ ? *reinterpret_cast<const uint4*>(wp1 + (kt_) * HBK_) : z4;            \
-        rw2 = ok_ ? *reinterpret_cast<const uint4*>(wp2 + (kt_) * HBK_) : z4;            \
-        rw3 = ok_ ? *reinterpret_cast<const uint4*>(wp3 + (kt_) * HBK_) : z4;            \
+        if (NPASS == 4) {                                                                \
+            ra2 = ok_ ? *reinterpret_cast<const uint4*>(ap2 + (kt_) * HBK_) : z4;        \
+            ra3 = ok_ ? *reinterpret_cast<const uint4*>(ap3 + (kt_) * HBK_) : z4;        \
+            rw2 = ok_ ? *reinterpret_cast<const uint4*>(wp2 + (kt_) * HBK_) : z4;        \
+            rw3 = ok_ ? *reinterpret_cast<const uint4*>(wp3 + (kt_) * HBK_) : z4;        \
+        }                                                                                \
     } while (0)
 #define HG_STORE(buf_)                                                                       \
     do {                                                                                     \
         __half* As_ = smem + (buf_) * (2 * HBM_ * HLD_) + r0 * HLD_ + c8 * 8;                \
         __half* Ws_ = As_ + HBM_ * HLD_;                                                     \
-        *reinterpret_cast<uint4*>(As_) = ra0; *reinterpret_cast<uint4*>(As_ + 32 * HLD_) = ra1;           \
-        *reinterpret_cast<uint4*>(As_ + 64 * HLD_) = ra2; *reinterpret_cast<uint4*>(As_ + 96 * HLD_) = ra3; \
-        *reinterpret_cast<uint4*>(Ws_) = rw0; *reinterpret_cast<uint4*>(Ws_ + 32 * HLD_) = rw1;           \
-        *reinterpret_cast<uint4*>(Ws_ + 64 * HLD_) = rw2; *reinterpret_cast<uint4*>(Ws_ + 96 * HLD_) = rw3; \
+        *reinterpret_cast<uint4*>(As_) = ra0; *reinterpret_cast<uint4*>(As_ + RPP * HLD_) = ra1;          \
+        *reinterpret_cast<uint4*>(Ws_) = rw0; *reinterpret_cast<uint4*>(Ws_ + RPP * HLD_) = rw1;          \
+        if (NPASS == 4) {                                                                                 \
+            *reinterpret_cast<uint4*>(As_ + 2 * RPP * HLD_) = ra2; *reinterpret_cast<uint4*>(As_ + 3 * RPP * HLD_) = ra3; \
+            *reinterpret_cast<uint4*>(Ws_ + 2 * RPP * HLD_) = rw2; *reinterpret_cast<uint4*>(Ws_ + 3 * RPP * HLD_) = rw3; \
+        }                                                                                                 \
     } while (0)
 
     f32x4 acc[4][4];
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmParams p) {
         const __half* As = smem + cur * (2 * HBM_ * HLD_) + (wr * 64 + l15) * HLD_ + 8 * kq;
         const __half* Ws = smem + cur * (2 * HBM_ * HLD_) + HBM_ * HLD_ + (wc * 64 + l15) * HLD_ + 8 * kq;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < HBK_ / 32; ++s) {
             h8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -227,15 +250,26 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
     static bool attr_set = false;
+    static int bk = 32;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HGEMM_SMEM);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HGEMM_SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<64>());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<64>());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
         if (e != hipSuccess) return e;
+        const char* ev = getenv("WT_HGEMM_BK");
+        if (ev && (atoi(ev) == 32 || atoi(ev) == 64)) bk = atoi(ev);
         attr_set = true;
     }
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
-    if (out_half) hipLaunchKernelGGL(gemm_f16_kernel<true>, dim3(nbx * nby), dim3(256), HGEMM_SMEM, s, p);
-    else hipLaunchKernelGGL(gemm_f16_kernel<false>, dim3(nbx * nby), dim3(256), HGEMM_SMEM, s, p);
+    const dim3 grid(nbx * nby);
+    if (bk == 64) {
+        if (out_half) hipLaunchKernelGGL((gemm_f16_kernel<true, 64>), grid, dim3(256), hgemm_smem<64>(), s, p);
+        else hipLaunchKernelGGL((gemm_f16_kernel<false, 64>), grid, dim3(256), hgemm_smem<64>(), s, p);
+    } else {
+        if (out_half) hipLaunchKernelGGL((gemm_f16_kernel<true, 32>), grid, dim3(256), hgemm_smem<32>(), s, p);
+        else hipLaunchKernelGGL((gemm_f16_kernel<false, 32>), grid, dim3(256), hgemm_smem<32>(), s, p);
+    }
     return hipGetLastError();
 }
 
