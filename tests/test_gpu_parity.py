@@ -102,3 +102,35 @@ def test_batches_larger_than_eight_are_chunked(wt):
     for b in (0, 7, 8, 10):
         one = dec.generate(hidden[b:b + 1]).cpu().numpy()[0]
         np.testing.assert_array_equal(ids[b, :len(one)], one)
+
+
+def test_bitwise_reproducible_across_runs(wt):
+    """No atomics on data and a fixed merge order in the split attention: two runs give bit-identical logits and ids."""
+    z, cfg, weights, mel = load_case("toy-wide_b2")
+    enc, dec = _engines(wt, cfg, weights)
+    x = torch.from_numpy(mel).cuda()
+    B, V, ml = mel.shape[0], cfg["vocab_size"], cfg["max_length"]
+    outs = []
+    for _ in range(2):
+        hidden = enc(x)
+        trace = torch.zeros(B, ml - 1, V, dtype=torch.float32, device="cuda")
+        ids = dec.generate(hidden, logits_trace=trace)
+        outs.append((hidden.cpu(), trace.cpu(), ids.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_stepwise_api_and_noop_steps_after_stop(wt):
+    """begin / steps / poll: steps enqueued past the stop test must not change the result (toy-short-eosall stops at length 5)."""
+    z, cfg, weights, mel = load_case("toy-short-eosall_b3")
+    enc, dec = _engines(wt, cfg, weights)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    dec.begin(hidden)
+    dec.steps(3)
+    cur, nu, done = dec.poll()
+    assert (cur, done) == (4, False) and nu == 3
+    dec.steps(9)                      # the stop fires after one more step; the other eight are no-ops
+    cur, nu, done = dec.poll()
+    assert (cur, nu, done) == (5, 0, True)
+    np.testing.assert_array_equal(dec.read_ids(cur).cpu().numpy(), z["ids"])
+    with pytest.raises(RuntimeError):
+        wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg).steps(1)   # steps before begin

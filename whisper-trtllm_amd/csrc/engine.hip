@@ -719,7 +719,7 @@ extern "C" int wt_decoder_greedy(wt_engine* e, const float* enc_hidden, int B, c
     while (!done) {
         const int remaining = p->max_length - cur;
         if (remaining <= 0) break;
-        const int chunk = remaining < 16 ? remaining : 16;  // one host round-trip per 16 tokens
+        const int chunk = remaining < 8 ? remaining : 8;  // one host round-trip per 8 tokens (<= 7 wasted steps after the stop)
         if ((rc = wt_decoder_steps(e, chunk, stream))) return rc;
         if ((rc = wt_decoder_poll(e, &cur, &nu, &done, stream))) return rc;
     }
