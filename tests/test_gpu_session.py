@@ -128,3 +128,32 @@ def test_run_py_flow_matches_golden(wt, tmp_path):
         stop = np.where(want[1:] == cfg["eos_token_id"])[0]
         n = (stop[0] + 2) if len(stop) else len(want)
         np.testing.assert_array_equal(got, want[:n])
+
+
+def test_fast_path_argument_errors(wt):
+    """The C-ABI returns negative codes + a message (never throws); the shim raises RuntimeError with that message."""
+    import ctypes
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 5)
+    enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights))
+    dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
+    hidden = enc(torch.from_numpy(wt.synthetic.make_mel(cfg, 0, 2)).cuda())
+    with pytest.raises(ValueError):
+        enc(torch.zeros(1, 80, 100, device="cuda"))                         # wrong frame count
+    with pytest.raises(ValueError):
+        dec.begin(hidden[:, :10])                                           # wrong encoder memory shape
+    with pytest.raises(RuntimeError, match="max_length"):
+        dec.begin(hidden, max_length=cfg["max_target_positions"] + 5)       # beyond max_target_positions
+    bad = dict(cfg)
+    bad["suppress_tokens"] = [cfg["vocab_size"] + 3]
+    with pytest.raises(RuntimeError, match="outside the vocabulary"):
+        wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), bad).begin(hidden)
+    lib = wt._lib.load()
+    nine = torch.zeros(9, cfg["max_source_positions"], cfg["d_model"], device="cuda")
+    dec.begin(hidden)
+    rc = lib.wt_decoder_begin(dec.session.handle, nine.data_ptr(), 9, ctypes.byref(dec._p), None)
+    assert rc == -38 and "shard the batch" in wt._lib.last_error()          # WT_E_UNSUPPORTED: > 8 utterances per call
+    assert lib.wt_encoder_forward(dec.session.handle, nine.data_ptr(), 1, nine.data_ptr(), None) == -22   # decoder handle
+    # the engine still works after the failed calls
+    ids = dec.generate(hidden)
+    assert ids.shape[0] == 2
