@@ -131,7 +131,8 @@ def test_encoder_attention(lib, B, S, H, scale):
 @pytest.mark.parametrize("N,K,xmode,act,use_res", [
     (384, 384, 1, 0, False), (1152, 384, 1, 0, False), (1536, 384, 1, 1, False), (384, 1536, 0, 0, True),
     (1024, 1024, 1, 0, True), (1024, 4096, 0, 0, True), (768, 3072, 0, 1, False), (1001, 128, 1, 0, False),
-    (130, 2048, 0, 0, False), (7, 512, 0, 0, False)])
+    (130, 2048, 0, 0, False), (7, 512, 0, 0, False),
+    (2304, 768, 1, 0, False), (768, 768, 0, 0, True), (1536, 512, 1, 1, False), (512, 2048, 0, 0, True)])   # small.en / base.en widths
 def test_skinny(lib, B, N, K, xmode, act, use_res):
     X, W, b = _rand(B, K, seed=9, scale=2.0) + 0.3, _rand(N, K, seed=10, scale=K ** -0.5), _rand(N, seed=11)
     g, be = _rand(K, seed=12) + 1.0, _rand(K, seed=13)

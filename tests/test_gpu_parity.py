@@ -134,3 +134,27 @@ def test_stepwise_api_and_noop_steps_after_stop(wt):
     np.testing.assert_array_equal(dec.read_ids(cur).cpu().numpy(), z["ids"])
     with pytest.raises(RuntimeError):
         wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg).steps(1)   # steps before begin
+
+
+@pytest.mark.parametrize("cname,seed", [("toy-short", 41), ("toy-wide", 42)])
+def test_full_batch_of_eight_matches_oracle(wt, cname, seed):
+    """B = 8 (the batch the metric is quoted on; NB=8 kernel instantiations) end to end against the CPU oracle."""
+    import cpu_ref
+    cfg = wt.synthetic.get_config(cname)
+    weights = wt.synthetic.make_weights(cfg, seed)
+    mel = wt.synthetic.make_mel(cfg, index=100 + seed, batch=8)
+    enc, dec = _engines(wt, cfg, weights)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    V, ml = cfg["vocab_size"], cfg["max_length"]
+    trace = torch.zeros(8, ml - 1, V, dtype=torch.float32, device="cuda")
+    ids = dec.generate(hidden, logits_trace=trace).cpu().numpy()
+    W = cpu_ref.to_torch(weights)
+    with torch.no_grad():
+        ref_hidden = cpu_ref.encoder_forward(W, cfg, torch.from_numpy(mel))
+        ref_ids, ref_logits = cpu_ref.greedy_search(W, cfg, ref_hidden, return_logits=True)
+    assert (hidden.cpu() - ref_hidden).abs().max().item() < 2e-4
+    steps = ref_ids.shape[1] - 1
+    margin = torch.topk(ref_logits, 2, dim=-1).values
+    assert (margin[..., 0] - margin[..., 1]).min().item() > 1e-4, "oracle has a near-tie; pick another seed"
+    assert (trace[:, :steps].cpu() - ref_logits).abs().max().item() < 1e-3
+    np.testing.assert_array_equal(ids, ref_ids.numpy())
