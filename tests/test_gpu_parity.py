@@ -158,3 +158,19 @@ def test_full_batch_of_eight_matches_oracle(wt, cname, seed):
     assert (margin[..., 0] - margin[..., 1]).min().item() > 1e-4, "oracle has a near-tie; pick another seed"
     assert (trace[:, :steps].cpu() - ref_logits).abs().max().item() < 1e-3
     np.testing.assert_array_equal(ids, ref_ids.numpy())
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_batch_width_is_row_independent(wt, B):
+    """All batch widths 1..8 (NB = 2/4/8 instantiations with zero-padded rows): row b equals the utterance decoded alone."""
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 55)
+    enc, dec = _engines(wt, cfg, weights)
+    mel = torch.from_numpy(wt.synthetic.make_mel(cfg, index=500, batch=8)).cuda()
+    singles = getattr(test_every_batch_width_is_row_independent, "_singles", None)
+    if singles is None:
+        singles = [dec.generate(enc(mel[b:b + 1])).cpu().numpy()[0] for b in range(8)]
+        test_every_batch_width_is_row_independent._singles = singles
+    ids = dec.generate(enc(mel[:B])).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(ids[b], singles[b])
