@@ -127,7 +127,7 @@ def test_encoder_attention(lib, B, S, H, scale):
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 12, 16])
 @pytest.mark.parametrize("N,K,xmode,act,use_res", [
     (384, 384, 1, 0, False), (1152, 384, 1, 0, False), (1536, 384, 1, 1, False), (384, 1536, 0, 0, True),
     (1024, 1024, 1, 0, True), (1024, 4096, 0, 0, True), (768, 3072, 0, 1, False), (1001, 128, 1, 0, False),

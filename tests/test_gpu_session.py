@@ -149,10 +149,10 @@ def test_fast_path_argument_errors(wt):
     with pytest.raises(RuntimeError, match="outside the vocabulary"):
         wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), bad).begin(hidden)
     lib = wt._lib.load()
-    nine = torch.zeros(9, cfg["max_source_positions"], cfg["d_model"], device="cuda")
+    nine = torch.zeros(17, cfg["max_source_positions"], cfg["d_model"], device="cuda")
     dec.begin(hidden)
-    rc = lib.wt_decoder_begin(dec.session.handle, nine.data_ptr(), 9, ctypes.byref(dec._p), None)
-    assert rc == -38 and "shard the batch" in wt._lib.last_error()          # WT_E_UNSUPPORTED: > 8 utterances per call
+    rc = lib.wt_decoder_begin(dec.session.handle, nine.data_ptr(), 17, ctypes.byref(dec._p), None)
+    assert rc == -38 and "shard the batch" in wt._lib.last_error()          # WT_E_UNSUPPORTED: > 16 utterances per call
     assert lib.wt_encoder_forward(dec.session.handle, nine.data_ptr(), 1, nine.data_ptr(), None) == -22   # decoder handle
     # the engine still works after the failed calls
     ids = dec.generate(hidden)

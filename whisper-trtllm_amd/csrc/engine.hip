@@ -595,7 +595,7 @@ static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int ro
 extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, const wt_greedy_params* p, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_begin: not a decoder engine");
     if (!enc_hidden || !p || B < 1) return fail(WT_E_INVALID, "wt_decoder_begin: bad arguments");
-    if (B > 8) return fail(WT_E_UNSUPPORTED, "wt_decoder_begin: batch %d > 8 per call; shard the batch (8 per GPU)", B);
+    if (B > 16) return fail(WT_E_UNSUPPORTED, "wt_decoder_begin: batch %d > 16 per call; shard the batch", B);
     if (p->max_length < 2 || p->max_length > e->T) return fail(WT_E_INVALID, "max_length %d outside [2, max_target_positions=%d]", p->max_length, e->T);
     auto tok_ok = [&](int t) { return t >= 0 && t < e->V; };
     if (!tok_ok(p->decoder_start_token_id) || !tok_ok(p->eos_token_id) || !tok_ok(p->pad_token_id))

@@ -61,20 +61,22 @@ hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, co
 }
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM
-// y[b][n] = epi(sum_k X(b)[k] W[n][k] + bias[n]) for NB <= 8 batch rows: W is streamed from HBM exactly once.
-// A wave owns a K-slice of <= 1024 columns (the whole row when K <= 1024): its slice of all NB activation rows
-// stays in registers for the life of the kernel (NB x 4 float4), W rows arrive as coalesced 1 KiB wave loads
-// (float4 per lane), two rows per iteration with the next pair prefetched.  The 2*NB per-lane partial sums are
-// reduced across the wave by a halving butterfly (v_permlane32_swap, v_permlane16_swap, then DPP row
-// rotations), leaving each (row, batch) total in one lane, which applies the epilogue.
-// When K > 1024 the 4 waves of a block split K (nsplit = 2 or 4) and combine through LDS.
-template <int NB, bool W_NT>
-__global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
-                                                             const int rows_per_group) {
-    __shared__ float comb[2][4][2 * NB];
-    __shared__ __attribute__((aligned(16))) float xs[NB][1024];
+// y[b][n] = epi(sum_k X(b)[k] W[n][k] + bias[n]) for NB <= 16 batch rows: W is streamed from HBM exactly once.
+// A wave owns a K-slice of <= 256*V columns: its slice of all NB activation rows stays in registers for the life of the
+// kernel (NB x V float4; V = 4 for NB <= 8, V = 2 for NB = 16), W rows arrive as coalesced 1 KiB wave loads (float4
+// per lane), two rows per iteration with the next pair prefetched.  The 2*NB per-lane partial sums are reduced
+// across the wave by a halving butterfly (v_permlane32_swap, v_permlane16_swap, then DPP row rotations), leaving
+// each (row, batch) total in one lane, which applies the epilogue.  When K exceeds a slice, the NW waves of a block
+// split K (nsplit = 2, 4 or 8) and combine through LDS.  Whole activation rows (K <= 1024) are staged -- and
+// LayerNorm-ed -- once per block through LDS.
+template <int NB, int V, int NW, bool W_NT>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
+                                                                             const int rows_per_group) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    float(*xs)[1024] = reinterpret_cast<float(*)[1024]>(sk_smem);                       // [NB][1024]
+    float(*comb)[NW][2 * NB] = reinterpret_cast<float(*)[NW][2 * NB]>(sk_smem + NB * 1024);  // [2][NW][2*NB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = 4 / nsplit;
+    const int G = NW / nsplit;
     const int sp = wave % nsplit, grp = wave / nsplit;
     const int ks0 = sp * KS;                       // first column of this wave's slice
     const int kend = min(p.K, ks0 + KS);           // one past its last column
@@ -82,18 +84,18 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
     const int row_begin = (int)min((long long)p.N, group_id * rows_per_group);
     const int row_end = min(p.N, row_begin + rows_per_group);
 
-    float4 xr[NB][4];
-    bool kok[4];
+    float4 xr[NB][V];
+    bool kok[V];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) kok[v] = (ks0 + 4 * lane + 256 * v) < kend;
+    for (int v = 0; v < V; ++v) kok[v] = (ks0 + 4 * lane + 256 * v) < kend;
     // ---- stream W ----------------------------------------------------------------------------------------------
-    float4 wbuf[2][2][4];
+    float4 wbuf[2][2][V];
     auto wload = [&](int buf, int row) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const float* wp = p.W + (size_t)min(row + r, p.N - 1) * p.K + ks0 + 4 * lane;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < V; ++v) {
                 if (W_NT) {  // weights are read exactly once per step: non-temporal (streaming) loads
                     typedef float f4v __attribute__((ext_vector_type(4)));
                     f4v t = f4v{0.f, 0.f, 0.f, 0.f};
@@ -108,30 +110,33 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
     if (row_begin < row_end) wload(0, row_begin);
 
     // ---- activation slice -> registers -------------------------------------------------------------------
-    if (nsplit == 1 && !(p.xmode == XMODE_PLAIN && p.x_direct)) {
-        // every wave of the block needs the same NB whole rows: stage them once per block through LDS.
-        // Wave w loads (and LayerNorm-s) rows w, w+4, ...; after the barrier each wave pulls all rows to registers.
+    if (p.K <= 1024 && !(p.xmode == XMODE_PLAIN && p.x_direct)) {
+        // every wave of the block needs (a slice of) the same NB whole rows: stage them once per block through LDS.
+        // Wave w loads (and LayerNorm-s) rows w and w + NW; after the barrier each wave pulls its slice of all rows.
+        bool kfull[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) kfull[v] = (4 * lane + 256 * v) < p.K;
         // gamma/beta are requested together with the rows (not after the statistics) to keep them off the critical path
         float4 g[4], be[4];
         if (p.xmode == XMODE_LAYERNORM) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {  // gamma = beta = 0 outside the row, so padding lanes stay 0
-                g[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-                be[v] = kok[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g[v] = kfull[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                be[v] = kfull[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         float4 xv[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int b = wave + 4 * j;
+            const int b = wave + NW * j;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                xv[j][v] = (kok[v] && b < p.B && b < NB) ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + 4 * lane + 256 * v)
-                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[j][v] = (kfull[v] && b < p.B && b < NB) ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + 4 * lane + 256 * v)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int b = wave + 4 * j;
+            const int b = wave + NW * j;
             if (b >= NB) break;
             if (p.xmode == XMODE_LAYERNORM) {
                 float sum = 0.f;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
                 float q = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    if (kok[v]) {
+                    if (kfull[v]) {
                         float a = xv[j][v].x - mean, c = xv[j][v].y - mean, e = xv[j][v].z - mean, f = xv[j][v].w - mean;
                         q += (a * a + c * c) + (e * e + f * f);
                     }
@@ -161,12 +166,13 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xr[b][v] = *reinterpret_cast<const float4*>(&xs[b][4 * lane + 256 * v]);
-    } else {  // K split over the block's waves: each wave owns a different K-slice, nothing to share
+            for (int v = 0; v < V; ++v)
+                xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][ks0 + 4 * lane + 256 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < V; ++v)
                 xr[b][v] = (kok[v] && b < p.B)
                                ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + ks0 + 4 * lane + 256 * v)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
                 for (int b = 0; b < NB; ++b) {
                     float a = 0.f;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < V; ++v) {
                         const float4 w = wbuf[cur][r][v];
                         a = fmaf(w.x, xr[b][v].x, a);
                         a = fmaf(w.y, xr[b][v].y, a);
@@ -262,32 +268,44 @@ __global__ __launch_bounds__(256, 2) void skinny_gemm_kernel(const SkinnyParams 
     }
 }
 
-hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
-    if (p.B < 1 || p.B > 8 || (p.K & 3)) return hipErrorInvalidValue;
+template <int NB, int V, int NW>
+static hipError_t skinny_launch_cfg(const SkinnyParams& p, hipStream_t s) {
     int nsplit = 1;
-    while (p.K / nsplit > 1024 || (p.K % nsplit)) {
+    while (p.K / nsplit > 256 * V || (p.K % nsplit)) {
         nsplit *= 2;
-        if (nsplit > 4) return hipErrorInvalidValue;
+        if (nsplit > NW) return hipErrorInvalidValue;
     }
     const int KS = p.K / nsplit;
     if (KS & 3) return hipErrorInvalidValue;
-    if (nsplit > 1 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;
-    const int G = 4 / nsplit;
+    if (p.K > 1024 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;  // LayerNorm needs whole rows staged in LDS
+    const int G = NW / nsplit;
     const int target_groups = 2048 / nsplit;  // 256 CUs x 8 waves
     int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
     if (rows_per_group < 2) rows_per_group = 2;
     const int groups = (p.N + rows_per_group - 1) / rows_per_group;
     const int grid = (groups + G - 1) / G;
-#define WT_SKINNY_LAUNCH(NB_)                                                                                          \
-    do {                                                                                                               \
-        if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB_, true>), dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);  \
-        else hipLaunchKernelGGL((skinny_gemm_kernel<NB_, false>), dim3(grid), dim3(256), 0, s, p, nsplit, KS, rows_per_group);        \
-    } while (0)
-    if (p.B <= 2) WT_SKINNY_LAUNCH(2);
-    else if (p.B <= 4) WT_SKINNY_LAUNCH(4);
-    else WT_SKINNY_LAUNCH(8);
-#undef WT_SKINNY_LAUNCH
+    constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true>), dim3(grid), dim3(64 * NW), smem, s, p, nsplit, KS, rows_per_group);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false>), dim3(grid), dim3(64 * NW), smem, s, p, nsplit, KS, rows_per_group);
     return hipGetLastError();
+}
+
+hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
+    if (p.B < 1 || p.B > 16 || (p.K & 3)) return hipErrorInvalidValue;
+    if (p.B <= 2) return skinny_launch_cfg<2, 4, 4>(p, s);
+    if (p.B <= 4) return skinny_launch_cfg<4, 4, 4>(p, s);
+    if (p.B <= 8) return skinny_launch_cfg<8, 4, 4>(p, s);
+    return skinny_launch_cfg<16, 2, 8>(p, s);  // 16 rows: half-width K-slices, 8 waves per block
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention

@@ -166,7 +166,7 @@ class WhisperDecoderEngine:
         if self.session.info.kind != 2:
             raise ValueError("not a WhisperDecoder engine")
         self.config = config
-        self.max_batch = 8
+        self.max_batch = 16   # utterances per engine call (wt_decoder_begin); larger batches are chunked by generate()
 
     def _params(self, max_length, force_eos_step, logits_trace):
         cfg = self.config
@@ -233,7 +233,7 @@ class WhisperDecoderEngine:
         no-ops for the token bookkeeping but still stream the weights, so a smaller chunk wastes less work on short
         transcripts (<= chunk-1 steps) at the price of one ~30 us host round trip per chunk."""
         if encoder_hidden.shape[0] > self.max_batch:
-            # larger batches (e.g. BASELINE config 4, B=16) run as consecutive engine batches of <= 8 utterances;
+            # larger batches run as consecutive engine batches of <= 16 utterances;
             # rows are independent, so the result is the concatenation (shorter groups are right-padded with pad_token_id)
             import torch
             if logits_trace is not None:
