@@ -87,3 +87,28 @@ def test_gpu_frontend_batched_and_feeds_the_encoder():
     enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, wt.synthetic.make_weights(cfg, 2)))
     hidden = enc(mel)
     assert tuple(hidden.shape) == (3, 1500, cfg["d_model"]) and torch.isfinite(hidden).all()
+
+
+@pytest.mark.gpu
+def test_waveform_to_token_ids_end_to_end():
+    """waveform -> GPU log-mel -> encoder -> greedy decode, against the same chain on the CPU oracle.  The front-end's
+    fp32-vs-fp64 difference (<= 2e-3 on clamped features) must not move the encoder memory by more than 1e-2 of its range."""
+    import whisper_trtllm_amd as wt
+    cfg = wt.synthetic.get_config("toy")               # 1500-frame encoder memory, i.e. real 30 s inputs
+    weights = wt.synthetic.make_weights(cfg, 9)
+    wavs = np.stack([synthetic_waveform(20 + i, 30.0) for i in range(2)])
+    fe = wt.audio.LogMelFrontend()
+    enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights))
+    dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
+    hidden = enc(fe(torch.from_numpy(wavs).cuda()))
+    ids = dec.generate(hidden).cpu().numpy()
+    W = cpu_ref.to_torch(weights)
+    mel_ref = torch.from_numpy(np.stack([cpu_ref.log_mel_spectrogram(w_) for w_ in wavs]))
+    with torch.no_grad():
+        h_ref = cpu_ref.encoder_forward(W, cfg, mel_ref)
+        ids_ref, logits_ref = cpu_ref.greedy_search(W, cfg, h_ref, return_logits=True)
+    assert (hidden.cpu() - h_ref).abs().max().item() < 1e-2 * h_ref.abs().max().item()
+    top2 = torch.topk(logits_ref, 2, dim=-1).values
+    if (top2[..., 0] - top2[..., 1]).min().item() > 5e-2:   # only compare ids when the oracle's choices are clear-cut
+        np.testing.assert_array_equal(ids, ids_ref.numpy())
+    assert ids.shape == tuple(ids_ref.shape)
