@@ -21,6 +21,8 @@ int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const float* bias, co
 int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream);
 /* qkv [B*S][3*H*64] -> ctx [B*S][H*64], softmax(QK^T/8)V per head */
 int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, void* stream);
+/* same with fp16 qkv / ctx (fp32 scores, softmax and accumulators) */
+int wt_dbg_encoder_attention_f16(const void* qkv, void* ctx, int B, int S, int H, void* stream);
 /* Y[B][N] = act((X' W^T + bias) * scale) (+ resid); xmode 0: X'=X[B][K], 1: X'=LayerNorm(X) */
 int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const float* W, const float* bias,
                   const float* resid, float* Y, int B, int N, int K, int xmode, int act, float scale, void* stream);

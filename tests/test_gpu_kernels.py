@@ -127,6 +127,26 @@ def test_encoder_attention(lib, B, S, H, scale):
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,S,H,scale", [(1, 64, 1, 1.0), (2, 96, 2, 1.0), (1, 1500, 2, 1.0), (2, 160, 3, 3.0), (1, 129, 1, 1.0), (1, 200, 1, 12.0)])
+def test_encoder_attention_f16(lib, B, S, H, scale):
+    d = 64 * H
+    qkv = (_rand(B * S, 3 * d, seed=8, scale=scale)).half()
+    if scale >= 12.0:  # late running-max jump in the last KV tile
+        qkv[5, :64] = 3.0
+        qkv[S - 3, d:d + 64] = 3.0
+    ctx = torch.empty(B * S, d, device="cuda", dtype=torch.float16)
+    qkv_d = qkv.cuda()
+    assert lib.wt_dbg_encoder_attention_f16(P(qkv_d), P(ctx), B, S, H, _stream()) == 0
+    torch.cuda.synchronize()
+    t = qkv.double().view(B, S, 3, H, 64)            # the fp16 inputs are exact in fp64
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * S, d)
+    got = ctx.cpu().double()
+    assert torch.isfinite(got).all()
+    # P is rounded to fp16 before the second product and the output is fp16: ~1e-3 relative
+    assert (got - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 12, 16])
 @pytest.mark.parametrize("N,K,xmode,act,use_res", [
     (384, 384, 1, 0, False), (1152, 384, 1, 0, False), (1536, 384, 1, 1, False), (384, 1536, 0, 0, True),

@@ -120,6 +120,9 @@ def bench_enc_attn(B=8, S=1500, H=16):
     ctx = torch.empty(B * S, 64 * H, device="cuda")
     us = timeit(lambda i: lib.wt_dbg_encoder_attention(P(qkv), P(ctx), B, S, H, ST()), 1, iters=5)
     print(f"enc_attn B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")
+    qkv_h, ctx_h = qkv.half(), ctx.half()
+    us = timeit(lambda i: lib.wt_dbg_encoder_attention_f16(P(qkv_h), P(ctx_h), B, S, H, ST()), 1, iters=5)
+    print(f"enc_attn_f16 B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")
 
 
 def bench_dec_attn_resident(B=8, H=16, S=1500):

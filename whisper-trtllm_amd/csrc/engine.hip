@@ -388,14 +388,13 @@ static int encoder_forward_f16(wt_engine* e, const float* mel, int B, float* out
     for (int i = 0; i < e->L; ++i) {
         const EncLayerW& l = e->enc_layers[i];
         LAUNCH(launch_layernorm_h(e->hbuf, l.ln1_w, l.ln1_b, e->x_h, M, d, s));
-        if ((rc = dense(e->x_h, d, l.qkv_w, l.qkv_b, 3 * d, e->qkv, 0, nullptr, false))) return rc;
+        if ((rc = dense(e->x_h, d, l.qkv_w, l.qkv_b, 3 * d, e->qkv, 0, nullptr, true))) return rc;   // q|k|v as fp16
         {
             hipEvent_t a, b;
             timer_begin(e, e->t_enc_attn, s, &a, &b);
-            LAUNCH(launch_encoder_attention(e->qkv, e->ctx, B, S, e->H, s));
+            LAUNCH(launch_encoder_attention_f16(e->qkv, e->ctx_h, B, S, e->H, s));                      // fp16 in/out, fp32 softmax
             timer_end(e, e->t_enc_attn, s, a, b);
         }
-        LAUNCH(launch_cast_h(e->ctx, e->ctx_h, (size_t)M * d, s));
         if ((rc = dense(e->ctx_h, d, l.o_w, l.o_b, d, e->hbuf, 0, e->hbuf, false))) return rc;
         LAUNCH(launch_layernorm_h(e->hbuf, l.ln2_w, l.ln2_b, e->x_h, M, d, s));
         if ((rc = dense(e->x_h, d, l.fc1_w, l.fc1_b, e->F, e->ffn_h, 1, nullptr, true))) return rc;

@@ -273,4 +273,155 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ fp16 encoder attention
+// softmax(Q K^T / 8) V with fp16 operands on v_mfma_f32_32x32x16_f16, fp32 scores / softmax / accumulators (the reference
+// forces fp32 scores in fp16 builds too, model.py:292-295).  Same transposed formulation as the fp32 kernel:
+//   S^T[key][query] = K . Q^T  -> the query sits on the lane, softmax statistics are lane-local;
+//   O^T[dv][query] += V^T . P^T -> P goes from the S^T accumulator registers straight into the next MFMA's B operand
+//                                  (registers 8t..8t+7 = k-step t; their key order 16t + 8(j>>2) + 4h + (j&3) is matched
+//                                  by reading V^T with the same permutation from a TRANSPOSED V tile in LDS).
+// qkv fp16 [B*S][3d] -> ctx fp16 [B*S][d].  128 queries per block (4 waves x 32), 64-key tiles, double-buffered LDS:
+// K rows padded to 144 B (conflict-free ds_read_b128), V^T rows to 136 B (conflict-free ds_read_b64).
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int HA_BQ = 128, HA_BKV = 64, HA_KLD = 72, HA_VLD = 68;           // strides in halfs
+constexpr int HA_TILE = HA_BKV * HA_KLD + HEAD_DIM * HA_VLD;                 // halfs per (K, V^T) stage
+constexpr int HA_SMEM = 2 * HA_TILE * 2;                                     // 35,840 B
+
+__global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __restrict__ qkv, __half* __restrict__ ctx, int S, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ha_raw[];
+    _Float16* smem = reinterpret_cast<_Float16*>(ha_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * HA_BQ;
+    const int d = H * HEAD_DIM, ld = 3 * d;
+    const _Float16* base = reinterpret_cast<const _Float16*>(qkv) + (size_t)b * S * ld + h * HEAD_DIM;
+
+    const int qrow = q0 + wave * 32 + l31;
+    h8 qf[4];  // Q[query][16s + 8h .. +7], pre-scaled by 64^-0.5 (exact in fp16)
+    {
+        const _Float16* qp = base + (size_t)min(qrow, S - 1) * ld + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = *reinterpret_cast<const h8*>(qp + 16 * s);
+            qf[s] *= (_Float16)0.125f;
+        }
+    }
+    // staging: 64 keys x 8 sixteen-byte chunks per matrix; thread -> chunk c8 (8 head dims), keys r0 and r0 + 32
+    const int c8 = tid & 7, r0 = tid >> 3;
+    const _Float16* gbase = base + c8 * 8;
+    h8 rk0, rk1, rv0, rv1;
+#define HA_GLOAD(kv0_)                                                                         \
+    do {                                                                                       \
+        const _Float16* rp0 = gbase + (size_t)min((kv0_) + r0, S - 1) * ld;                    \
+        const _Float16* rp1 = gbase + (size_t)min((kv0_) + r0 + 32, S - 1) * ld;               \
+        rk0 = *reinterpret_cast<const h8*>(rp0 + d); rv0 = *reinterpret_cast<const h8*>(rp0 + 2 * d); \
+        rk1 = *reinterpret_cast<const h8*>(rp1 + d); rv1 = *reinterpret_cast<const h8*>(rp1 + 2 * d); \
+    } while (0)
+#define HA_LSTORE(buf_)                                                                        \
+    do {                                                                                       \
+        _Float16* Ks_ = smem + (buf_) * HA_TILE;                                               \
+        _Float16* Vt_ = Ks_ + HA_BKV * HA_KLD;                                                 \
+        *reinterpret_cast<h8*>(Ks_ + r0 * HA_KLD + c8 * 8) = rk0;                              \
+        *reinterpret_cast<h8*>(Ks_ + (r0 + 32) * HA_KLD + c8 * 8) = rk1;                       \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                     \
+            Vt_[(c8 * 8 + e_) * HA_VLD + r0] = rv0[e_];                                        \
+            Vt_[(c8 * 8 + e_) * HA_VLD + r0 + 32] = rv1[e_];                                   \
+        }                                                                                      \
+    } while (0)
+
+    f32x16h o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (S + HA_BKV - 1) / HA_BKV;
+    HA_GLOAD(0);
+    HA_LSTORE(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, kv0 = t * HA_BKV;
+        if (t + 1 < ntiles) HA_GLOAD(kv0 + HA_BKV);
+        const _Float16* Ks = smem + cur * HA_TILE;
+        const _Float16* Vt = Ks + HA_BKV * HA_KLD;
+
+        f32x16h s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+        const _Float16* kp = Ks + l31 * HA_KLD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 k0 = *reinterpret_cast<const h8*>(kp + 16 * s);
+            const h8 k1 = *reinterpret_cast<const h8*>(kp + 32 * HA_KLD + 16 * s);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+        }
+        if (kv0 + HA_BKV > S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __expf(s0[r] - m_new);
+            s1[r] = __expf(s1[r] - m_new);
+            ps += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        // P.V: k-step (kt, t2) covers keys kt*32 + 16*t2 .. +15; B fragment = accumulator registers 8*t2 .. 8*t2+7
+        const _Float16* vp = Vt + l31 * HA_VLD + 4 * hh;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                h8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (_Float16)(kt == 0 ? s0[8 * t2 + j] : s1[8 * t2 + j]);
+                const int kb = kt * 32 + 16 * t2;
+                const h4 a00 = *reinterpret_cast<const h4*>(vp + kb), a01 = *reinterpret_cast<const h4*>(vp + kb + 8);
+                const h4 a10 = *reinterpret_cast<const h4*>(vp + 32 * HA_VLD + kb), a11 = *reinterpret_cast<const h4*>(vp + 32 * HA_VLD + kb + 8);
+                const h8 va0 = {a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
+                const h8 va1 = {a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va1, pf, o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) HA_LSTORE(cur ^ 1);
+        __syncthreads();
+    }
+#undef HA_GLOAD
+#undef HA_LSTORE
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (qrow < S) {
+        _Float16* op = reinterpret_cast<_Float16*>(ctx) + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const h4 v0 = {(_Float16)(o0[4 * g] * inv), (_Float16)(o0[4 * g + 1] * inv), (_Float16)(o0[4 * g + 2] * inv), (_Float16)(o0[4 * g + 3] * inv)};
+            const h4 v1 = {(_Float16)(o1[4 * g] * inv), (_Float16)(o1[4 * g + 1] * inv), (_Float16)(o1[4 * g + 2] * inv), (_Float16)(o1[4 * g + 3] * inv)};
+            *reinterpret_cast<h4*>(op + 8 * g) = v0;
+            *reinterpret_cast<h4*>(op + 32 + 8 * g) = v1;
+        }
+    }
+}
+
+hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S, int H, hipStream_t s) {
+    dim3 grid((S + HA_BQ - 1) / HA_BQ, H, B);
+    hipLaunchKernelGGL(enc_attn_f16_kernel, grid, dim3(256), HA_SMEM, s, (const __half*)qkv, (__half*)ctx, S, H);
+    return hipGetLastError();
+}
+
 }  // namespace wt
