@@ -81,6 +81,8 @@ struct wt_engine {
     float *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
     float *dh = nullptr, *dq = nullptr, *datt = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
     int* att_cnt = nullptr;
+    float* sel_val = nullptr;
+    int* sel_idx = nullptr;
     DecState* st = nullptr;
     int *ids = nullptr, *unfinished = nullptr, *forced = nullptr;
     uint8_t* mask = nullptr;
@@ -467,6 +469,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     const size_t o_sk = take(kv_self * 4), o_sv = take(kv_self * 4), o_ck = take(kv_cross * 4), o_cv = take(kv_cross * 4);
     const size_t o_h = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
     const size_t o_cnt = take((size_t)B * e->H * 4);
+    const size_t o_selv = take((size_t)B * 8 * 4), o_seli = take((size_t)B * 8 * 4);
     const size_t o_part = take((size_t)B * e->H * 16 * PART_STRIDE * 4), o_lg = take((size_t)B * e->V * 4);
     const size_t o_st = take(sizeof(DecState)), o_ids = take((size_t)B * cap_len * 4), o_unf = take((size_t)B * 4);
     const size_t o_forced = take((size_t)(cap_len + 1) * 4), o_mask = take((size_t)e->V);
@@ -474,7 +477,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for decoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     char* b = e->dec_ws;
     e->self_k = (float*)(b + o_sk); e->self_v = (float*)(b + o_sv); e->cross_k = (float*)(b + o_ck); e->cross_v = (float*)(b + o_cv);
-    e->dh = (float*)(b + o_h); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
+    e->dh = (float*)(b + o_h); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->sel_val = (float*)(b + o_selv); e->sel_idx = (int*)(b + o_seli); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
     e->logits = (float*)(b + o_lg); e->st = (DecState*)(b + o_st); e->ids = (int*)(b + o_ids); e->unfinished = (int*)(b + o_unf);
     e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask);
     HIPCHK(hipMemset(e->att_cnt, 0, (size_t)B * e->H * 4));  // arrival tickets start (and are left) at zero
@@ -505,11 +508,12 @@ struct StepIO {
     float *cross_k, *cross_v;              // layer stride = B*H*S*64
     float* logits;                         // [B][V]
     int B, nsplit_self, nsplit_cross;
+    bool embed;                            // launch the input-embedding kernel (the fast path gets it from greedy_finish)
 };
 
 static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
     const int d = e->d, B = io.B, H = e->H;
-    LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
+    if (io.embed) LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
     SkinnyParams k;
     DecAttnParams a;
     for (int i = 0; i < e->L; ++i) {
@@ -633,6 +637,7 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     e->nsplit_self = 1;
     e->nsplit_cross = pick_splits(B, e->H, e->S);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
+    LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s));  // input of step 0
     rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, s);
     if (rc) return rc;
     e->begun = true;
@@ -644,6 +649,7 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
     io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
+    io.embed = false;  // dh already holds this step's input: written by wt_decoder_begin (step 0) or by the previous greedy_finish
     int rc = enqueue_step(e, io, s);
     if (rc) return rc;
     SelectParams sp;
@@ -651,6 +657,8 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     sp.logits = e->logits; sp.mask = e->mask; sp.forced = e->forced; sp.ids = e->ids; sp.unfinished = e->unfinished;
     sp.st = e->st; sp.trace = e->trace; sp.B = e->B; sp.V = e->V; sp.max_length = e->max_length;
     sp.begin_index = e->begin_index; sp.eos = e->eos; sp.pad = e->pad; sp.force_eos_step = e->force_eos_step;
+    sp.part_val = e->sel_val; sp.part_idx = e->sel_idx; sp.tok_emb = e->tok_emb; sp.pos_emb = e->pos_emb; sp.next_x = e->dh;
+    sp.d_model = e->d;
     LAUNCH(launch_greedy_select(sp, s));
     return WT_OK;
 }
@@ -859,6 +867,7 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     io.ids = data; io.ids_ld = 1; io.self_k = nsk; io.self_v = nsv; io.self_cap = cache_len + 1;
     io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1;
     io.nsplit_self = 1; io.nsplit_cross = pick_splits(1, e->H, S);
+    io.embed = true;
     e->begun = false;  // the resident greedy state is clobbered by this call
     return enqueue_step(e, io, s);
 }

@@ -448,14 +448,18 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ greedy select
 // logits processors + argmax + pad/EOS bookkeeping + append, on device (run.py:199-226; HF utils.py:1502-1526;
-// processors logits_process.py:1281-1328 in the order Suppress -> SuppressAtBegin -> Force).  One block per
-// utterance; the shared step counters are advanced afterwards by greedy_advance_kernel.
-__global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams p) {
-    __shared__ float s_val[16];
-    __shared__ int s_idx[16];
+// processors logits_process.py:1281-1328 in the order Suppress -> SuppressAtBegin -> Force).  Two launches:
+//   greedy_select_kernel  grid (SELECT_CHUNKS, B): masked partial argmax of one vocabulary chunk (lowest index on ties);
+//   greedy_finish_kernel  one block: final argmax per row, forced / pad / EOS rules, append, advance the step counters,
+//                         stop test, and the NEXT step's input embedding (embed_tokens[tok] + embed_positions[pos]).
+constexpr int SELECT_CHUNKS = 8;
+
+__global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
     const DecState* st = p.st;
     if (st->done) return;  // steps enqueued past the stop test are no-ops
-    const int tid = threadIdx.x, b = blockIdx.x, cur_len = st->cur_len, step = st->step;
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y, cur_len = st->cur_len, step = st->step;
     const bool at_begin = cur_len == p.begin_index;
     const float* lg = p.logits + (size_t)b * p.V;
     float* tr = p.trace ? p.trace + ((size_t)b * (p.max_length - 1) + step) * p.V : nullptr;
@@ -469,12 +473,13 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams 
         }
     };
     if ((p.V & 3) == 0) {  // 16-byte path, several independent loads in flight per thread
-        const int n4 = p.V >> 2;
+        const int n4 = p.V >> 2, per = (n4 + SELECT_CHUNKS - 1) / SELECT_CHUNKS;
+        const int i0 = chunk * per, i1 = min(n4, i0 + per);
         const float4* lg4 = reinterpret_cast<const float4*>(lg);
         const uchar4* mk4 = reinterpret_cast<const uchar4*>(p.mask);
         float4* tr4 = reinterpret_cast<float4*>(tr);
 #pragma unroll 4
-        for (int i = tid; i < n4; i += 1024) {
+        for (int i = i0 + tid; i < i1; i += 256) {
             const float4 x = lg4[i];
             const uchar4 m = mk4[i];
             if (tr) tr4[i] = x;
@@ -484,7 +489,9 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams 
             consider(x.w, m.w, 4 * i + 3);
         }
     } else {
-        for (int v = tid; v < p.V; v += 1024) {
+        const int per = (p.V + SELECT_CHUNKS - 1) / SELECT_CHUNKS;
+        const int v0 = chunk * per, v1 = min(p.V, v0 + per);
+        for (int v = v0 + tid; v < v1; v += 256) {
             const float x = lg[v];
             if (tr) tr[v] = x;
             consider(x, p.mask[v], v);
@@ -505,11 +512,33 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams 
     }
     __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < 16; ++i)
+        for (int i = 1; i < 4; ++i)
             if (s_val[i] > best || (s_val[i] == best && s_idx[i] < bidx)) {
                 best = s_val[i];
                 bidx = s_idx[i];
             }
+        p.part_val[b * SELECT_CHUNKS + chunk] = best;
+        p.part_idx[b * SELECT_CHUNKS + chunk] = bidx;
+    }
+}
+
+__global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p) {
+    __shared__ int s_tok[16];
+    __shared__ int s_pos;
+    DecState* st = p.st;
+    if (st->done) return;
+    const int tid = threadIdx.x, cur_len = st->cur_len, step = st->step;
+    if (tid < p.B) {
+        const int b = tid;
+        float best = p.part_val[b * SELECT_CHUNKS];
+        int bidx = p.part_idx[b * SELECT_CHUNKS];
+        for (int c = 1; c < SELECT_CHUNKS; ++c) {  // chunks are in increasing index order: strict > keeps the lowest index on ties
+            const float v = p.part_val[b * SELECT_CHUNKS + c];
+            if (v > best) {
+                best = v;
+                bidx = p.part_idx[b * SELECT_CHUNKS + c];
+            }
+        }
         int tok = bidx;
         const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
         if (forced >= 0) tok = forced;
@@ -517,24 +546,35 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const SelectParams 
         if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
         p.ids[(size_t)b * p.max_length + cur_len] = tok;
         if (tok == p.eos) p.unfinished[b] = 0;
+        s_tok[b] = tok;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nu = 0;
+        for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
+        st->n_unfinished = nu;
+        st->cur_len = cur_len + 1;
+        st->pos += 1;
+        st->self_len += 1;
+        st->step = step + 1;
+        if (nu == 0 || cur_len + 1 >= p.max_length) st->done = 1;  // run.py:219-226
+        s_pos = st->pos;
+    }
+    __syncthreads();
+    if (!p.next_x || cur_len + 1 >= p.max_length) return;
+    // input of the next step: x[b] = embed_tokens[tok_b] + embed_positions[pos]   (model.py:423-425)
+    const int d4 = p.d_model >> 2;
+    const float4* pe = reinterpret_cast<const float4*>(p.pos_emb + (size_t)s_pos * p.d_model);
+    for (int i = tid; i < p.B * d4; i += 256) {
+        const int b = i / d4, c = i - b * d4;
+        const float4 a = reinterpret_cast<const float4*>(p.tok_emb + (size_t)s_tok[b] * p.d_model)[c], q = pe[c];
+        reinterpret_cast<float4*>(p.next_x + (size_t)b * p.d_model)[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
     }
 }
-__global__ void greedy_advance_kernel(const SelectParams p) {
-    DecState* st = p.st;
-    if (st->done) return;
-    int nu = 0;
-    for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
-    const int cur_len = st->cur_len + 1;
-    st->n_unfinished = nu;
-    st->cur_len = cur_len;
-    st->pos += 1;
-    st->self_len += 1;
-    st->step += 1;
-    if (nu == 0 || cur_len >= p.max_length) st->done = 1;  // run.py:219-226
-}
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(greedy_select_kernel, dim3(p.B), dim3(1024), 0, s, p);
-    hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(1), 0, s, p);
+    if (p.B > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(SELECT_CHUNKS, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(greedy_finish_kernel, dim3(1), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

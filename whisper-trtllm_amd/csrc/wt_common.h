@@ -119,6 +119,12 @@ struct SelectParams {
     int* unfinished;       // [B]
     DecState* st;
     float* trace;          // optional [B][max_length-1][V]
+    float* part_val;       // scratch [B][8] partial maxima
+    int* part_idx;         // scratch [B][8]
+    const float* tok_emb;  // next-step embedding: embed_tokens [V][d], embed_positions [T][d]
+    const float* pos_emb;
+    float* next_x;         // [B][d] decoder input of the next step, or nullptr
+    int d_model;
     int B, V, max_length, begin_index, eos, pad, force_eos_step;
 };
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s);
