@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch16", action="store_true", help="skip the secondary batch-16 measurement")
-    ap.add_argument("--cpu-decode-steps", type=int, default=6)
+    ap.add_argument("--cpu-decode-steps", type=int, default=128, help="decoder steps timed on the CPU (about 10 s of CPU work in total)")
     ap.add_argument("--encoder-precision", default="float32", choices=["float32", "float16"],
                     help="float16 = BASELINE config 4 (fp16 encoder + fp32 decoder); the headline metric is float32")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
