@@ -157,3 +157,23 @@ def test_fast_path_argument_errors(wt):
     # the engine still works after the failed calls
     ids = dec.generate(hidden)
     assert ids.shape[0] == 2
+
+
+def test_c_abi_greedy_convenience_call(wt):
+    """wt_decoder_greedy (begin + steps/poll loop inside the library) returns the golden ids and the stop length."""
+    import ctypes
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights))
+    dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
+    hidden = enc(torch.from_numpy(mel).cuda()).contiguous()
+    p = dec._params(None, None, None)
+    ml = cfg["max_length"]
+    ids = torch.zeros(3, ml, dtype=torch.int32, device="cuda")
+    out_len = ctypes.c_int()
+    lib = wt._lib.load()
+    lib.wt_decoder_greedy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(wt._lib.GreedyParams),
+                                      ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    rc = lib.wt_decoder_greedy(dec.session.handle, hidden.data_ptr(), 3, ctypes.byref(p), ids.data_ptr(), ctypes.byref(out_len), None)
+    assert rc == 0, wt._lib.last_error()
+    assert out_len.value == z["ids"].shape[1]
+    np.testing.assert_array_equal(ids[:, :out_len.value].cpu().numpy(), z["ids"])
