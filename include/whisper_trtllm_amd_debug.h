@@ -30,6 +30,16 @@ int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const fl
  * part: scratch [B][H][n_split][68]; cnt: int [B][H], must be zero on entry and is left zero */
 int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt, float* out,
                             int B, int H, int s_cap, int len, int n_split, void* stream);
+/* the same with the folded query: `u` [B][H*64] is finished per row as (u - mean(ln_h[b]) * ln_r) * rstd(ln_h[b]) + ln_t
+ * (LayerNorm statistics of ln_h [B][H*64], eps 1e-5) before the attention — DESIGN.md §4, builder.py:_fold_cross_query */
+int wt_dbg_decode_attention_folded(const float* u, const float* kcache, const float* vcache, float* part, int* cnt, float* out,
+                                   const float* ln_h, const float* ln_r, const float* ln_t, int B, int H, int s_cap, int len,
+                                   int n_split, void* stream);
+/* two skinny GEMMs in one launch: Ya = Xa . Wa^T + bias_a + resid_a ([B][Na], K = Ka) and
+ * Yb = [Xb ; Xb2] . Wb^T + bias_b ([B][Nb], K = Kb = 2 * columns of Xb) */
+int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka,
+                       const float* Xb, const float* Xb2, const float* Wb, const float* bias_b, float* Yb, int Nb, int Kb, int B,
+                       void* stream);
 
 #ifdef __cplusplus
 }

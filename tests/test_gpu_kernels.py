@@ -193,3 +193,51 @@ def test_decode_attention(lib, B, H, cap, length, n_split):
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,cap,length,n_split", [(1, 2, 40, 17, 1), (3, 6, 1500, 1500, 2), (8, 16, 1500, 1500, 2), (2, 3, 160, 5, 4),
+                                                    (5, 8, 96, 96, 3)])
+def test_decode_attention_folded_query(lib, B, H, cap, length, n_split):
+    """Cross-attention with the folded query (builder.py:_fold_cross_query): the kernel finishes
+    q = (u - mean(h1).r).rstd(h1) + t from the LayerNorm statistics of the residual row; d = 64 H covers 128..1024."""
+    d = 64 * H
+    u, h1 = _rand(B, d, seed=21) * 0.5, _rand(B, d, seed=22) * 2.0 + 0.7
+    r, t = _rand(d, seed=23), _rand(d, seed=24) * 0.3
+    k, v = _rand(B, H, cap, 64, seed=16), _rand(B, H, cap, 64, seed=17)
+    part = torch.full((B, H, n_split, 68), float("nan"), device="cuda")
+    cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+    out = torch.full((B, d), float("nan"), device="cuda")
+    ud, hd, rd, td, kd, vd = u.cuda(), h1.cuda(), r.cuda(), t.cuda(), k.cuda(), v.cuda()
+    for _ in range(2):
+        assert lib.wt_dbg_decode_attention_folded(P(ud), P(kd), P(vd), P(part), P(cnt), P(out), P(hd), P(rd), P(td), B, H, cap, length,
+                                                  n_split, _stream()) == 0
+    torch.cuda.synchronize()
+    h64 = h1.double()
+    mu = h64.mean(1, keepdim=True)
+    rstd = (h64.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    q = ((u.double() - mu * r.double()) * rstd + t.double()).view(B, H, 1, 64)
+    att = torch.softmax(q @ k.double()[:, :, :length].transpose(-1, -2), -1)
+    ref = (att @ v.double()[:, :, :length]).reshape(B, d)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 8, 11, 16])
+@pytest.mark.parametrize("d", [128, 384, 512, 768, 1024])
+def test_skinny_pair(lib, B, d):
+    """One launch = out-projection + residual (K = d, LDS-staged activations) and the concatenated-input GEMM
+    y = W.[a ; h] + c (K = 2d, two activation buffers): both halves against fp64 torch."""
+    a, h = _rand(B, d, seed=31), _rand(B, d, seed=32)
+    Wo, bo = _rand(d, d, seed=33, scale=d ** -0.5), _rand(d, seed=34)
+    Wf, c = _rand(d, 2 * d, seed=35, scale=(2 * d) ** -0.5), _rand(d, seed=36)
+    ad, hd, Wod, bod, Wfd, cd = a.cuda(), h.cuda(), Wo.cuda(), bo.cuda(), Wf.cuda(), c.cuda()
+    h1 = torch.full((B, d), float("nan"), device="cuda")
+    uo = torch.full((B, d), float("nan"), device="cuda")
+    assert lib.wt_dbg_skinny_pair(P(ad), P(Wod), P(bod), P(hd), P(h1), d, d, P(ad), P(hd), P(Wfd), P(cd), P(uo), d, 2 * d, B, _stream()) == 0
+    torch.cuda.synchronize()
+    ref1 = h.double() + a.double() @ Wo.double().T + bo.double()
+    ref2 = torch.cat([a, h], 1).double() @ Wf.double().T + c.double()
+    assert (h1.cpu().double() - ref1).abs().max().item() < 2e-5
+    assert (uo.cpu().double() - ref2).abs().max().item() < 2e-5
+    assert torch.equal(hd.cpu(), h)   # the residual input is read-only (h1 goes to the other buffer)

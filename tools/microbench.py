@@ -58,6 +58,24 @@ def bench_dec_attn(B=8, H=16, S=1500, L=24):
             print(f"dec_attn len={length} (cap {S}) n_split={ns}: {us:7.2f} us")
 
 
+def bench_dec_attn_folded(B=8, H=16, S=1500, L=24):
+    """cross-attention launch with the plain query vs the folded query (LayerNorm statistics finished in the kernel)"""
+    d = H * 64
+    q = torch.randn(B, d, device="cuda") * 0.3
+    h1 = torch.randn(B, d, device="cuda")
+    r, t = torch.randn(d, device="cuda"), torch.randn(d, device="cuda")
+    k = torch.randn(L, B, H, S, 64, device="cuda") * 0.5
+    v = torch.randn(L, B, H, S, 64, device="cuda") * 0.5
+    part = torch.empty(B * H * 16 * 68, device="cuda")
+    cnt = torch.zeros(B * H, dtype=torch.int32, device="cuda")
+    out = torch.empty(B, d, device="cuda")
+    mb = L and 2 * B * H * S * 64 * 4 / 1e6
+    us = timeit(lambda i: lib.wt_dbg_decode_attention(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), B, H, S, S, 2, ST()), L)
+    print(f"cross-attention plain  query: {us:6.2f} us  {mb / us:6.2f} TB/s")
+    us = timeit(lambda i: lib.wt_dbg_decode_attention_folded(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), P(h1), P(r), P(t), B, H, S, S, 2, ST()), L)
+    print(f"cross-attention folded query: {us:6.2f} us  {mb / us:6.2f} TB/s")
+
+
 def bench_skinny(B=8, L=24):
     for (N, K, xmode) in ((1024, 1024, 0), (1024, 1024, 4), (1024, 1024, 1), (1024, 1024, 5), (3072, 1024, 5), (4096, 1024, 5), (1024, 4096, 4), (51864, 1024, 5), (3072, 1024, 1), (4096, 1024, 1), (1024, 4096, 0), (51864, 1024, 1)):
         n_rot = L if N < 50000 else 4

@@ -34,3 +34,14 @@ dec.begin(hidden)
 print("33 steps + 3 polls %.2f ms" % t(lambda: (dec.begin(hidden, force_eos_step=32), dec.steps(16), dec.poll(), dec.steps(16), dec.poll(), dec.steps(16), dec.poll())))
 print("generate(eos@32)   %.2f ms" % t(lambda: dec.generate(hidden, force_eos_step=32)))
 print("enc + generate     %.2f ms" % t(lambda: dec.generate(enc(mel), force_eos_step=32)))
+for chunk in (4, 8, 16, 64, 447):
+    print("generate(447 steps, chunk=%3d) %.2f ms" % (chunk, t(lambda: dec.generate(hidden, chunk=chunk), 2)))
+dec.begin(hidden)
+t0 = time.perf_counter()
+dec.steps(8)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("host time to enqueue 8 step graphs: %.3f ms" % ((t1 - t0) * 1e3))
+t0 = time.perf_counter()
+dec.poll()
+print("poll on an idle stream: %.3f ms" % ((time.perf_counter() - t0) * 1e3))

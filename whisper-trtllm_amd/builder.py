@@ -6,6 +6,8 @@ weight pack of engine_pack.py with the layout transforms the HIP kernels want:
   * conv weights [d, c, 1, 3] -> [d, 3*c] with k-major columns (implicit-GEMM order, csrc/engine.hip)
   * decoder self-attn q|k|v stacked to [3d, d] (k bias = 0), cross-attn k|v stacked to [2d, d]
   * proj_out aliased to embed_tokens when the two arrays are equal (tied embedding, modeling_whisper.py:1335)
+  * decoder cross-attention query folded through its LayerNorm and the self-attention out-projection
+    (`_fold_cross_query`): one dependent launch fewer per decoder layer
 """
 from __future__ import annotations
 
@@ -99,6 +101,23 @@ class Builder:
         prec = _dtypes.float16.code if half else _dtypes.float32.code
         return engine_pack.pack(engine_pack.KIND_ENCODER, prec, cfg, t)
 
+    @staticmethod
+    def _fold_cross_query(wq, bq, gamma, beta, wo, bo, scale=0.125):
+        """The cross-attention query of a decoder layer (model.py:261-272, 283-294; HF modeling_whisper.py:472, 727-735) is
+            q = s.(Wq.LN(h1) + bq),   h1 = h + Wo.a + bo   (a = self-attention context, s = head_dim^-0.5)
+        With G = s.Wq.diag(gamma) and (mu, rstd) the LayerNorm statistics of h1 this is
+            q = rstd.(G.h1 - mu.G.1) + s.(Wq.beta + bq),    G.h1 = [G.Wo | G].[a ; h] + G.bo
+        so the engine computes u = W_fold.[a ; h] + c in the SAME launch as h1 (both only need a and h) and the attention
+        kernel finishes q = (u - mu.r).rstd + t from the statistics of h1.  Products are formed in float64.
+        Returns (W_fold [d, 2d], c [d], r [d], t [d]) as float32."""
+        wq64, wo64 = wq.astype(np.float64), wo.astype(np.float64)
+        g = scale * wq64 * gamma.astype(np.float64)[None, :]
+        w_fold = np.concatenate([g @ wo64, g], axis=1)
+        c = g @ bo.astype(np.float64)
+        r = g.sum(axis=1)
+        t = scale * (wq64 @ beta.astype(np.float64) + bq.astype(np.float64))
+        return tuple(np.ascontiguousarray(x, dtype=np.float32) for x in (w_fold, c, r, t))
+
     def _pack_decoder(self, m: WhisperDecoder, val, f32) -> bytes:
         d = m.d_model
         zeros = np.zeros((d,), np.float32)
@@ -114,11 +133,14 @@ class Builder:
             t[sa + "qkv.weight"] = np.concatenate([val(sa + "q_proj.weight"), val(sa + "k_proj.weight"), val(sa + "v_proj.weight")], 0)
             t[sa + "qkv.bias"] = np.concatenate([val(sa + "q_proj.bias"), zeros, val(sa + "v_proj.bias")], 0)
             t[sa + "dense.weight"], t[sa + "dense.bias"] = val(sa + "dense.weight"), val(sa + "dense.bias")
-            t[ca + "q_proj.weight"], t[ca + "q_proj.bias"] = val(ca + "q_proj.weight"), val(ca + "q_proj.bias")
+            fold = self._fold_cross_query(val(ca + "q_proj.weight"), val(ca + "q_proj.bias"), val(p + "encoder_attn_layer_norm.weight"),
+                                          val(p + "encoder_attn_layer_norm.bias"), val(sa + "dense.weight"), val(sa + "dense.bias"))
+            for n, a in zip(("weight", "bias", "rowsum", "shift"), fold):
+                t[ca + "q_fold." + n] = a
             t[ca + "kv.weight"] = np.concatenate([val(ca + "k_proj.weight"), val(ca + "v_proj.weight")], 0)
             t[ca + "kv.bias"] = np.concatenate([zeros, val(ca + "v_proj.bias")], 0)
             t[ca + "dense.weight"], t[ca + "dense.bias"] = val(ca + "dense.weight"), val(ca + "dense.bias")
-            for n in ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"):
+            for n in ("self_attn_layer_norm", "final_layer_norm"):
                 t[p + n + ".weight"], t[p + n + ".bias"] = val(p + n + ".weight"), val(p + n + ".bias")
             for n in ("fc1", "fc2"):
                 t[p + n + ".weight"], t[p + n + ".bias"] = val(p + n + ".weight"), val(p + n + ".bias")

@@ -40,6 +40,26 @@ extern "C" int wt_dbg_decode_attention(const float* q, const float* kcache, cons
     a.fixed_len = len;
     return rc_of(launch_dec_attn(a, (hipStream_t)stream));
 }
+extern "C" int wt_dbg_decode_attention_folded(const float* u, const float* kcache, const float* vcache, float* part, int* cnt,
+                                              float* out, const float* ln_h, const float* ln_r, const float* ln_t, int B, int H,
+                                              int s_cap, int len, int n_split, void* stream) {
+    if (len < 1 || len > s_cap || n_split < 1 || n_split > 16 || !ln_h || !ln_r || !ln_t || H * 64 > 1024) return -22;
+    DecAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = u; a.kcache = kcache; a.vcache = vcache; a.part = part; a.cnt = cnt; a.out = out; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
+    a.fixed_len = len; a.ln_h = ln_h; a.ln_r = ln_r; a.ln_t = ln_t;
+    return rc_of(launch_dec_attn(a, (hipStream_t)stream));
+}
+extern "C" int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka,
+                                  const float* Xb, const float* Xb2, const float* Wb, const float* bias_b, float* Yb, int Nb, int Kb,
+                                  int B, void* stream) {
+    SkinnyParams a, b;
+    memset(&a, 0, sizeof a);
+    memset(&b, 0, sizeof b);
+    a.X = Xa; a.W = Wa; a.bias = bias_a; a.resid = resid_a; a.Y = Ya; a.B = B; a.N = Na; a.K = Ka; a.q_scale = 1.f; a.w_nt = 1;
+    b.X = Xb; b.X2 = Xb2; b.x_direct = 1; b.W = Wb; b.bias = bias_b; b.Y = Yb; b.B = B; b.N = Nb; b.K = Kb; b.q_scale = 1.f; b.w_nt = 1;
+    return rc_of(launch_skinny_pair(a, b, (hipStream_t)stream));
+}
 
 extern "C" int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N,
                                int K, int act, int out_half, void* stream) {

@@ -49,7 +49,8 @@ struct EncLayerW {
 };
 struct DecLayerW {
     const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b;
-    const float *ln2_w, *ln2_b, *cq_w, *cq_b, *ckv_w, *ckv_b, *co_w, *co_b;
+    const float *fold_w, *fold_c, *fold_r, *fold_t;  // folded LN + cross-attention query (builder.py:_pack_decoder)
+    const float *ckv_w, *ckv_b, *co_w, *co_b;
     const float *ln3_w, *ln3_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 
@@ -79,7 +80,7 @@ struct wt_engine {
     int dec_cap = 0, dec_maxlen_cap = 0;
     char* dec_ws = nullptr;
     float *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
-    float *dh = nullptr, *dq = nullptr, *datt = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
+    float *dh = nullptr, *dh2 = nullptr, *dq = nullptr, *datt = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
     int* att_cnt = nullptr;
     float* sel_val = nullptr;
     int* sel_idx = nullptr;
@@ -168,7 +169,7 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
     BlobHeader hd;
     memcpy(&hd, blob, sizeof hd);
     if (memcmp(hd.magic, "WTENGINE", 8) != 0) return fail(WT_E_INVALID, "engine blob has bad magic");
-    if (hd.version != 1) return fail(WT_E_UNSUPPORTED, "engine blob version %u not supported", hd.version);
+    if (hd.version != 2) return fail(WT_E_UNSUPPORTED, "engine blob version %u not supported (this library reads version 2; rebuild the engine)", hd.version);
     if (hd.total_bytes != nbytes || hd.table_off + (uint64_t)hd.n_tensors * sizeof(BlobTensor) > nbytes ||
         hd.data_off > nbytes)
         return fail(WT_E_INVALID, "engine blob is truncated or corrupt (header says %llu bytes, got %zu)",
@@ -286,8 +287,8 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
             l.ln1_w = need(p + "self_attn_layer_norm.weight", {d}); l.ln1_b = need(p + "self_attn_layer_norm.bias", {d});
             l.qkv_w = need(p + "self_attn.qkv.weight", {3 * d, d}); l.qkv_b = need(p + "self_attn.qkv.bias", {3 * d});
             l.o_w = need(p + "self_attn.dense.weight", {d, d}); l.o_b = need(p + "self_attn.dense.bias", {d});
-            l.ln2_w = need(p + "encoder_attn_layer_norm.weight", {d}); l.ln2_b = need(p + "encoder_attn_layer_norm.bias", {d});
-            l.cq_w = need(p + "encoder_attn.q_proj.weight", {d, d}); l.cq_b = need(p + "encoder_attn.q_proj.bias", {d});
+            l.fold_w = need(p + "encoder_attn.q_fold.weight", {d, 2 * d}); l.fold_c = need(p + "encoder_attn.q_fold.bias", {d});
+            l.fold_r = need(p + "encoder_attn.q_fold.rowsum", {d}); l.fold_t = need(p + "encoder_attn.q_fold.shift", {d});
             l.ckv_w = need(p + "encoder_attn.kv.weight", {2 * d, d}); l.ckv_b = need(p + "encoder_attn.kv.bias", {2 * d});
             l.co_w = need(p + "encoder_attn.dense.weight", {d, d}); l.co_b = need(p + "encoder_attn.dense.bias", {d});
             l.ln3_w = need(p + "final_layer_norm.weight", {d}); l.ln3_b = need(p + "final_layer_norm.bias", {d});
@@ -464,7 +465,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_sk = take(kv_self * 4), o_sv = take(kv_self * 4), o_ck = take(kv_cross * 4), o_cv = take(kv_cross * 4);
-    const size_t o_h = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
+    const size_t o_h = take((size_t)B * d * 4), o_h2 = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
     const size_t o_cnt = take((size_t)B * e->H * 4);
     const size_t o_selv = take((size_t)B * 8 * 4), o_seli = take((size_t)B * 8 * 4);
     const size_t o_part = take((size_t)B * e->H * 16 * PART_STRIDE * 4), o_lg = take((size_t)B * e->V * 4);
@@ -474,7 +475,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for decoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     char* b = e->dec_ws;
     e->self_k = (float*)(b + o_sk); e->self_v = (float*)(b + o_sv); e->cross_k = (float*)(b + o_ck); e->cross_v = (float*)(b + o_cv);
-    e->dh = (float*)(b + o_h); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->sel_val = (float*)(b + o_selv); e->sel_idx = (int*)(b + o_seli); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
+    e->dh = (float*)(b + o_h); e->dh2 = (float*)(b + o_h2); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->sel_val = (float*)(b + o_selv); e->sel_idx = (int*)(b + o_seli); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
     e->logits = (float*)(b + o_lg); e->st = (DecState*)(b + o_st); e->ids = (int*)(b + o_ids); e->unfinished = (int*)(b + o_unf);
     e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask);
     HIPCHK(hipMemset(e->att_cnt, 0, (size_t)B * e->H * 4));  // arrival tickets start (and are left) at zero
@@ -509,17 +510,20 @@ struct StepIO {
 static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
     const int d = e->d, B = io.B, H = e->H;
     if (io.embed) LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
-    SkinnyParams k;
+    SkinnyParams k, k2;
     DecAttnParams a;
+    // The residual stream ping-pongs between two buffers once per layer: the self-attention out-projection (h1 = h + Wo.a)
+    // and the folded cross-attention query (which still reads h) share one launch, so h1 cannot overwrite h in place.
+    float *h = e->dh, *h1 = e->dh2;
     for (int i = 0; i < e->L; ++i) {
         const DecLayerW& l = e->dec_layers[i];
         float* sk = io.self_k + (size_t)i * B * H * io.self_cap * HEAD_DIM;
         float* sv = io.self_v + (size_t)i * B * H * io.self_cap * HEAD_DIM;
         const float* ck = io.cross_k + (size_t)i * B * H * e->S * HEAD_DIM;
         const float* cv = io.cross_v + (size_t)i * B * H * e->S * HEAD_DIM;
-        // --- self attention (model.py:273-281, 283-304): LN -> q|k|v, append k/v row in place, attend, out-proj + residual
+        // --- self attention (model.py:273-281, 283-304): LN -> q|k|v, append k/v row in place, attend
         memset(&k, 0, sizeof k);
-        k.X = e->dh; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
+        k.X = h; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
         k.Y = e->dq; k.kcache = sk; k.vcache = sv; k.st = e->st; k.B = B; k.N = 3 * d; k.K = d; k.ymode = YMODE_QKV_APPEND;
         k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
@@ -527,18 +531,20 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
         a.n_split = io.nsplit_self; a.fixed_len = 0;
         LAUNCH(launch_dec_attn(a, s));
+        // --- ONE launch: out-projection + residual (h1 = h + Wo.a + bo) and the folded cross-attention query
+        //     u = s.Wq.diag(gamma2).(h + Wo.a + bo) = fold_w.[a ; h] + fold_c; LayerNorm statistics of h1 are applied
+        //     by the cross-attention kernel (model.py:261-272 semantics, one dependent launch fewer per layer)
         memset(&k, 0, sizeof k);
-        k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = e->dh;
-        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
-        LAUNCH(launch_skinny(k, s));
-        // --- cross attention over the encoder memory (model.py:261-272): K/V already resident
-        memset(&k, 0, sizeof k);
-        k.X = e->dh; k.ln_w = l.ln2_w; k.ln_b = l.ln2_b; k.xmode = XMODE_LAYERNORM; k.W = l.cq_w; k.bias = l.cq_b;
-        k.Y = e->dq; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 0.125f; k.w_nt = 1;
-        LAUNCH(launch_skinny(k, s));
+        k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = h;
+        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
+        memset(&k2, 0, sizeof k2);
+        k2.X = e->datt; k2.X2 = h; k2.xmode = XMODE_PLAIN; k2.x_direct = 1; k2.W = l.fold_w; k2.bias = l.fold_c;
+        k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = 1;
+        LAUNCH(launch_skinny_pair(k, k2, s));
+        // --- cross attention over the encoder memory: K/V already resident
         memset(&a, 0, sizeof a);
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
-        a.n_split = io.nsplit_cross; a.fixed_len = e->S;
+        a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t;
         {
             hipEvent_t ta, tb;
             timer_begin(e, e->t_cross, s, &ta, &tb);
@@ -546,22 +552,23 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
             timer_end(e, e->t_cross, s, ta, tb);
         }
         memset(&k, 0, sizeof k);
-        k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = e->dh;
-        k.Y = e->dh; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
+        k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = h1;
+        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         // --- FFN (model.py:363-367)
         memset(&k, 0, sizeof k);
-        k.X = e->dh; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
+        k.X = h1; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
         k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
         memset(&k, 0, sizeof k);
-        k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = e->dh; k.Y = e->dh; k.st = e->st;
+        k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = h1; k.Y = h1; k.st = e->st;
         k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = 1;
         LAUNCH(launch_skinny(k, s));
+        std::swap(h, h1);
     }
     // final LN + vocabulary projection (model.py:455-457; logits are the engine's 'hidden_states' output)
     memset(&k, 0, sizeof k);
-    k.X = e->dh; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
+    k.X = h; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
     k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
     {
         hipEvent_t ta, tb;
@@ -886,6 +893,7 @@ extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* a
         a.vcache = e->cross_v + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
         a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = e->B; a.H = e->H; a.s_cap = e->S;
         a.n_split = e->nsplit_cross; a.fixed_len = e->S;
+        a.ln_h = e->dh2; a.ln_r = e->dec_layers[i].fold_r; a.ln_t = e->dec_layers[i].fold_t;  // as in the decode step
         le = launch_dec_attn(a, e->own_stream);
     }
     hipError_t ce = hipStreamEndCapture(e->own_stream, &g);

@@ -70,8 +70,8 @@ hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, co
 // split K (nsplit = 2, 4 or 8) and combine through LDS.  Whole activation rows (K <= 1024) are staged -- and
 // LayerNorm-ed -- once per block through LDS.
 template <int NB, int V, int NW, bool W_NT>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
-                                                                             const int rows_per_group) {
+__device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsplit, const int KS, const int rows_per_group,
+                                            const int block) {
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
     float(*xs)[1024] = reinterpret_cast<float(*)[1024]>(sk_smem);                       // [NB][1024]
     float(*comb)[NW][2 * NB] = reinterpret_cast<float(*)[NW][2 * NB]>(sk_smem + NB * 1024);  // [2][NW][2*NB]
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(c
     const int sp = wave % nsplit, grp = wave / nsplit;
     const int ks0 = sp * KS;                       // first column of this wave's slice
     const int kend = min(p.K, ks0 + KS);           // one past its last column
-    const long long group_id = (long long)blockIdx.x * G + grp;
+    const long long group_id = (long long)block * G + grp;
     const int row_begin = (int)min((long long)p.N, group_id * rows_per_group);
     const int row_end = min(p.N, row_begin + rows_per_group);
 
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(c
     if (row_begin < row_end) wload(0, row_begin);
 
     // ---- activation slice -> registers -------------------------------------------------------------------
-    if (p.K <= 1024 && !(p.xmode == XMODE_PLAIN && p.x_direct)) {
+    if (p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2))) {
         // every wave of the block needs (a slice of) the same NB whole rows: stage them once per block through LDS.
         // Wave w loads (and LayerNorm-s) rows w and w + NW; after the barrier each wave pulls its slice of all rows.
         bool kfull[4];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(c
 #pragma unroll
             for (int v = 0; v < V; ++v)
                 xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][ks0 + 4 * lane + 256 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
+    } else if (p.X2 == nullptr) {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -176,6 +176,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(c
                 xr[b][v] = (kok[v] && b < p.B)
                                ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + ks0 + 4 * lane + 256 * v)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {  // concatenated activations [X ; X2], K/2 columns each (K/2 is a multiple of 4: a float4 never straddles)
+        const int kh = p.K >> 1;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int col = ks0 + 4 * lane + 256 * v;
+                const float* src = col < kh ? p.X + (size_t)b * kh + col : p.X2 + (size_t)b * kh + (col - kh);
+                xr[b][v] = (kok[v] && b < p.B) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
     }
 
     // which (row, batch) total this lane ends up holding after the butterfly
@@ -268,8 +278,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(c
     }
 }
 
+struct SkinnyPlan {
+    int nsplit, KS, rows_per_group, grid;
+};
+
+template <int NB, int V, int NW, bool W_NT>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
+                                                                             const int rows_per_group) {
+    skinny_body<NB, V, NW, W_NT>(p, nsplit, KS, rows_per_group, blockIdx.x);
+}
+
+// Two GEMMs that depend on the same predecessor share ONE launch (the self-attention out-projection and the folded
+// cross-attention query): blocks [0, pa.grid) run `a`, the rest run `b`.  The branch is block-uniform.
 template <int NB, int V, int NW>
-static hipError_t skinny_launch_cfg(const SkinnyParams& p, hipStream_t s) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_pair_kernel(const SkinnyParams a, const SkinnyPlan pa,
+                                                                             const SkinnyParams b, const SkinnyPlan pb) {
+    if ((int)blockIdx.x < pa.grid) skinny_body<NB, V, NW, true>(a, pa.nsplit, pa.KS, pa.rows_per_group, blockIdx.x);
+    else skinny_body<NB, V, NW, true>(b, pb.nsplit, pb.KS, pb.rows_per_group, blockIdx.x - pa.grid);
+}
+
+template <int NB, int V, int NW>
+static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
+    if (p.B < 1 || p.B > NB || (p.K & 3)) return hipErrorInvalidValue;
     int nsplit = 1;
     while (p.K / nsplit > 256 * V || (p.K % nsplit)) {
         nsplit *= 2;
@@ -278,25 +308,53 @@ static hipError_t skinny_launch_cfg(const SkinnyParams& p, hipStream_t s) {
     const int KS = p.K / nsplit;
     if (KS & 3) return hipErrorInvalidValue;
     if (p.K > 1024 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;  // LayerNorm needs whole rows staged in LDS
+    if (p.X2 && (p.xmode != XMODE_PLAIN || (p.K & 7))) return hipErrorInvalidValue;
     const int G = NW / nsplit;
     const int target_groups = 2048 / nsplit;  // 256 CUs x 8 waves
     int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
     if (rows_per_group < 2) rows_per_group = 2;
     const int groups = (p.N + rows_per_group - 1) / rows_per_group;
-    const int grid = (groups + G - 1) / G;
+    out->nsplit = nsplit; out->KS = KS; out->rows_per_group = rows_per_group; out->grid = (groups + G - 1) / G;
+    return hipSuccess;
+}
+
+template <int NB, int V, int NW>
+static hipError_t skinny_smem_attr() {
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true>),
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false>),
+                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
-    if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true>), dim3(grid), dim3(64 * NW), smem, s, p, nsplit, KS, rows_per_group);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false>), dim3(grid), dim3(64 * NW), smem, s, p, nsplit, KS, rows_per_group);
+    return hipSuccess;
+}
+
+template <int NB, int V, int NW>
+static hipError_t skinny_launch_cfg(const SkinnyParams& p, hipStream_t s) {
+    SkinnyPlan pl;
+    hipError_t e = skinny_plan<NB, V, NW>(p, &pl);
+    if (e == hipSuccess) e = skinny_smem_attr<NB, V, NW>();
+    if (e != hipSuccess) return e;
+    constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
+    if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
+    return hipGetLastError();
+}
+
+template <int NB, int V, int NW>
+static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s) {
+    SkinnyPlan pa, pb;
+    hipError_t e = skinny_plan<NB, V, NW>(a, &pa);
+    if (e == hipSuccess) e = skinny_plan<NB, V, NW>(b, &pb);
+    if (e == hipSuccess) e = skinny_smem_attr<NB, V, NW>();
+    if (e != hipSuccess) return e;
+    constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
+    hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW>), dim3(pa.grid + pb.grid), dim3(64 * NW), smem, s, a, pa, b, pb);
     return hipGetLastError();
 }
 
@@ -306,6 +364,14 @@ hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
     if (p.B <= 4) return skinny_launch_cfg<4, 4, 4>(p, s);
     if (p.B <= 8) return skinny_launch_cfg<8, 4, 4>(p, s);
     return skinny_launch_cfg<16, 2, 8>(p, s);  // 16 rows: half-width K-slices, 8 waves per block
+}
+
+hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s) {
+    if (a.B != b.B || a.B < 1 || a.B > 16) return hipErrorInvalidValue;
+    if (a.B <= 2) return skinny_pair_cfg<2, 4, 4>(a, b, s);
+    if (a.B <= 4) return skinny_pair_cfg<4, 4, 4>(a, b, s);
+    if (a.B <= 8) return skinny_pair_cfg<8, 4, 4>(a, b, s);
+    return skinny_pair_cfg<16, 2, 8>(a, b, s);
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention
@@ -328,14 +394,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     const int s_begin = split * chunk, s_end = min(len, s_begin + chunk);
     const int d = p.H * HEAD_DIM;
 
-    const float4 q = *reinterpret_cast<const float4*>(p.q + (size_t)b * d + h * HEAD_DIM + 4 * c);
     const float* kb = p.kcache + ((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + 4 * c;
     const float* vb = p.vcache + ((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + 4 * c;
 
-    float m = -INFINITY, l = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = s_begin + sid; s0 < s_end; s0 += 16 * U) {
-        float4 kk[U], vv[U];
+    auto load_tile = [&](float4 (&kk)[U], float4 (&vv)[U], const int s0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = min(s0 + 16 * u, s_end - 1);
@@ -350,6 +412,48 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
                 vv[u] = *reinterpret_cast<const float4*>(vb + (size_t)key * HEAD_DIM);
             }
         }
+    };
+    // the first K/V tile is requested before the query prologue, whose loads and reductions then hide under its latency
+    const int s_first = s_begin + sid;
+    float4 kk[U], vv[U];
+    if (s_first < s_end) load_tile(kk, vv, s_first);
+
+    float4 q = *reinterpret_cast<const float4*>(p.q + (size_t)b * d + h * HEAD_DIM + 4 * c);
+    if (p.ln_h) {
+        // folded query: finish the LayerNorm of the residual row here (every wave for itself: d <= 1024 floats, no barrier),
+        // two-pass statistics like the LayerNorm kernels: q = (u - mean . r) * rstd + t
+        const float4 r4 = *reinterpret_cast<const float4*>(p.ln_r + h * HEAD_DIM + 4 * c);
+        const float4 t4 = *reinterpret_cast<const float4*>(p.ln_t + h * HEAD_DIM + 4 * c);
+        const float* hr = p.ln_h + (size_t)b * d;
+        float4 hv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)  // unconditional loads from clamped addresses, all four in flight before the first use
+            hv[v] = *reinterpret_cast<const float4*>(hr + min(4 * lane + 256 * v, d - 4));
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise serialises them: load, wait, select, next load)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (4 * lane + 256 * v >= d) hv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sum += (hv[v].x + hv[v].y) + (hv[v].z + hv[v].w);
+        const float mean = wave_allreduce_sum_d(sum) / d;
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if ((4 * lane + 256 * v) < d) {
+                const float a0 = hv[v].x - mean, a1 = hv[v].y - mean, a2 = hv[v].z - mean, a3 = hv[v].w - mean;
+                sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        const float rstd = rsqrtf(wave_allreduce_sum_d(sq) / d + 1e-5f);
+        q.x = (q.x - mean * r4.x) * rstd + t4.x;
+        q.y = (q.y - mean * r4.y) * rstd + t4.y;
+        q.z = (q.z - mean * r4.z) * rstd + t4.z;
+        q.w = (q.w - mean * r4.w) * rstd + t4.w;
+    }
+    float m = -INFINITY, l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = s_first; s0 < s_end; s0 += 16 * U) {  // (a register double buffer of the tiles measured 0.5-1 us SLOWER per launch)
+        if (s0 != s_first) load_tile(kk, vv, s0);
         float sc[U];
         float mx = m;
 #pragma unroll

@@ -59,7 +59,8 @@ enum { EPI_ROWMAJOR = 0, EPI_KV_HEADS = 1 };
 enum { XMODE_PLAIN = 0, XMODE_LAYERNORM = 1 };
 enum { YMODE_PLAIN = 0, YMODE_QKV_APPEND = 1 };
 struct SkinnyParams {
-    const float* X;        // [B][K]
+    const float* X;        // [B][K]  (with X2: [B][K/2], columns [0, K/2))
+    const float* X2;       // optional second activation [B][K/2] for columns [K/2, K): y = W . [X ; X2]  (x_direct path)
     const float* ln_w;     // LAYERNORM gamma/beta [K]
     const float* ln_b;
     const float* W;        // [N][K]
@@ -92,6 +93,11 @@ struct DecAttnParams {
     int B, H, s_cap;
     int n_split;
     int fixed_len;         // >0: number of keys (cross attention); 0: use st->self_len + 1
+    // folded cross-attention query: q holds u = s.Wq.diag(gamma).h1 (+ const) and the kernel finishes the
+    // LayerNorm per row: q = (u - mean(h1) . ln_r) * rstd(h1) + ln_t.  ln_h == nullptr: q is used as it is.
+    const float* ln_h;     // [B][d] residual stream whose LayerNorm statistics normalise q
+    const float* ln_r;     // [d] row sums of s.Wq.diag(gamma)
+    const float* ln_t;     // [d] s.(Wq.beta + bq)
 };
 
 // launchers (kernels_*.hip)
@@ -109,6 +115,8 @@ hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S
 hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
                             int d, const DecState* st, hipStream_t s);
 hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s);
+// two independent skinny GEMMs (same batch) in ONE launch: blocks [0, grid_a) run `a`, the rest run `b`
+hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s);
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s);
 
 struct SelectParams {

@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 import numpy as np
 
 MAGIC = b"WTENGINE"
-VERSION = 1
+VERSION = 2   # 2: decoder packs carry encoder_attn.q_fold.* instead of q_proj / encoder_attn_layer_norm
 KIND_ENCODER, KIND_DECODER = 1, 2
 _HDR = struct.Struct("<8sIIII24iQQQ")   # 144 bytes
 _TEN = struct.Struct("<96sII4qQQ")      # 152 bytes
