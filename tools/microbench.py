@@ -108,6 +108,17 @@ def bench_gemm(M=12000):
         print(f"gemm M={M} N={N} K={K} act={act}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_gemm_fixed(M=12000, N=1024):
+    """fixed per-tile cost of the fp32 GEMM: K sweep at constant output size (752 tiles = one round)"""
+    for K in (16, 64, 256, 512, 1024, 2048, 4096):
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(4, N, K, device="cuda") * 0.03
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, 0, ST()), 4, iters=20)
+        print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+
+
 def bench_gemm_f16(M=12000):
     for (N, K, act, oh) in ((3072, 1024, 0, 0), (1024, 1024, 0, 0), (4096, 1024, 1, 1), (1024, 4096, 0, 0), (1024, 3072, 1, 0)):
         A = torch.randn(M, K, device="cuda").half()

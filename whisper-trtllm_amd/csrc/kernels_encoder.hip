@@ -209,46 +209,81 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // Row-dependent addressing (batch split, output row pointer) is computed once per row -- the batch index of the
+    // wave's first row by ONE wave-uniform division, the rest by carry -- and the residual / position rows of a group of
+    // four rows are loaded together before they are used: in a one-round launch nothing overlaps the epilogue, and the
+    // per-element division + load-wait-use chain it replaces cost about a quarter of the K = 1024 launches.
+    int nn[2];
+    float bv[2];
+    bool nok[2];
+    int kv_which[2] = {0, 0}, kv_h[2] = {0, 0}, kv_j[2] = {0, 0};
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
-        const int n = n0 + wc * 64 + tj * 32 + l31;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-        int kv_which = 0, kv_h = 0, kv_j = 0;
+        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+        nok[tj] = nn[tj] < p.N;
+        bv[tj] = (p.bias && nok[tj]) ? p.bias[nn[tj]] : 0.f;
         if (p.epi == EPI_KV_HEADS) {
             const int dkv = p.kv_heads * HEAD_DIM;
-            kv_which = n / dkv;
-            const int nn = n - kv_which * dkv;
-            kv_h = nn / HEAD_DIM;
-            kv_j = nn - kv_h * HEAD_DIM;
+            kv_which[tj] = nn[tj] / dkv;
+            const int r2 = nn[tj] - kv_which[tj] * dkv;
+            kv_h[tj] = r2 / HEAD_DIM;
+            kv_j[tj] = r2 - kv_h[tj] * HEAD_DIM;
         }
+    }
+    const int mw = m0 + wr * 64;                       // first row of this wave (wave-uniform)
+    const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m >= p.M) continue;
-                float v = acc[ti][tj][r] + bv;
-                if (p.act) v = gelu_erf(v);
-                const int cb = m / p.c_rows_per_batch, cr = m - cb * p.c_rows_per_batch;
-                if (p.pos) v += p.pos[(long long)cr * p.N + n];
-                if (p.epi == EPI_ROWMAJOR) {
-                    const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
-                    if (p.resid) v += p.resid[off];
-                    p.C[off] = v;
-                } else {
-                    float* base = kv_which ? p.C2 : p.C;
-                    base[(((long long)cb * p.kv_heads + kv_h) * p.kv_cap + cr + p.kv_seq_off) * HEAD_DIM + kv_j] = v;
-                }
+        for (int rq = 0; rq < 4; ++rq) {
+            long long offs[4];
+            int crs[4];
+            bool mok[4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int o = ti * 32 + ri + 8 * rq + 4 * hh;
+                mok[ri] = mw + o < p.M;
+                int cb = cb_w, cr = cr_w + o;
+                while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
+                crs[ri] = cr;
+                offs[ri] = p.epi == EPI_ROWMAJOR ? (long long)cb * p.c_batch_stride + (long long)cr * p.ldc
+                                                 : (long long)cb * p.kv_heads * p.kv_cap * HEAD_DIM + (long long)(cr + p.kv_seq_off) * HEAD_DIM;
             }
+            float extra[4][2];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    extra[ri][tj] = (p.resid && mok[ri] && nok[tj]) ? p.resid[offs[ri] + nn[tj]] : 0.f;
+            float posv[4][2];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    posv[ri][tj] = (p.pos && mok[ri] && nok[tj]) ? p.pos[(long long)crs[ri] * p.N + nn[tj]] : 0.f;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    if (!(mok[ri] && nok[tj])) continue;
+                    float v = acc[ti][tj][rq * 4 + ri] + bv[tj];
+                    if (p.act) v = gelu_erf(v);
+                    v += posv[ri][tj];
+                    if (p.epi == EPI_ROWMAJOR) {
+                        p.C[offs[ri] + nn[tj]] = v + extra[ri][tj];
+                    } else {
+                        float* base = kv_which[tj] ? p.C2 : p.C;
+                        base[offs[ri] + (long long)kv_h[tj] * p.kv_cap * HEAD_DIM + kv_j[tj]] = v;
+                    }
+                }
         }
     }
 }
 
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
-    if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3)) return hipErrorInvalidValue;
+    if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3) || p.c_rows_per_batch < 1 || p.a_rows_per_batch < 1) return hipErrorInvalidValue;
     static bool attr_set = false;
     static int force_bk = 0;
     if (!attr_set) {
