@@ -89,28 +89,37 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
 #pragma unroll
     for (int v = 0; v < V; ++v) kok[v] = (ks0 + 4 * lane + 256 * v) < kend;
     // ---- stream W ----------------------------------------------------------------------------------------------
+    // Every load below is UNCONDITIONAL from a clamped address, with out-of-range lanes zeroed afterwards: a predicated
+    // load (`ok ? *p : 0`) compiles to an exec-masked branch whose merge copy makes the compiler wait for vmcnt(0) in the
+    // middle of the request burst -- one full HBM round trip before the remaining loads are even issued.
+    int kcol[V];   // this lane's column of slice chunk v, clamped into the slice
+#pragma unroll
+    for (int v = 0; v < V; ++v) kcol[v] = min(ks0 + 4 * lane + 256 * v, kend - 4);
     float4 wbuf[2][2][V];
     auto wload = [&](int buf, int row) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const float* wp = p.W + (size_t)min(row + r, p.N - 1) * p.K + ks0 + 4 * lane;
+            const float* wp = p.W + (size_t)min(row + r, p.N - 1) * p.K;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 if (W_NT) {  // weights are read exactly once per step: non-temporal (streaming) loads
                     typedef float f4v __attribute__((ext_vector_type(4)));
-                    f4v t = f4v{0.f, 0.f, 0.f, 0.f};
-                    if (kok[v]) t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(wp + 256 * v));
+                    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(wp + kcol[v]));
                     wbuf[buf][r][v] = make_float4(t[0], t[1], t[2], t[3]);
                 } else
-                    wbuf[buf][r][v] = kok[v] ? *reinterpret_cast<const float4*>(wp + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    wbuf[buf][r][v] = *reinterpret_cast<const float4*>(wp + kcol[v]);
             }
         }
     };
-    // the first two W rows are requested before the activation prologue so their HBM latency hides under it
-    if (row_begin < row_end) wload(0, row_begin);
-
+    // W values of clamped (out-of-slice) lanes are multiplied by activations that ARE zeroed below, so they need no fix-up
     // ---- activation slice -> registers -------------------------------------------------------------------
-    if (p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2))) {
+    // vmcnt retires in issue order, so whatever is requested first is waited for first: with LDS staging the activation
+    // rows (L2 / Infinity-Cache hits, ~1 us) go out BEFORE the first W rows (HBM, 2+ us under the burst) and the
+    // LayerNorm + staging + barrier run while the weights are still in flight; measured with in-kernel timestamps the
+    // other order left the whole prologue behind the arrival of the weights.
+    const bool staged = p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2));
+    if (!staged && row_begin < row_end) wload(0, row_begin);
+    if (staged) {
         // every wave of the block needs (a slice of) the same NB whole rows: stage them once per block through LDS.
         // Wave w loads (and LayerNorm-s) rows w and w + NW; after the barrier each wave pulls its slice of all rows.
         bool kfull[4];
@@ -118,22 +127,35 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         for (int v = 0; v < 4; ++v) kfull[v] = (4 * lane + 256 * v) < p.K;
         // gamma/beta are requested together with the rows (not after the statistics) to keep them off the critical path
         float4 g[4], be[4];
+        int fcol[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fcol[v] = min(4 * lane + 256 * v, p.K - 4);
         if (p.xmode == XMODE_LAYERNORM) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {  // gamma = beta = 0 outside the row, so padding lanes stay 0
-                g[v] = kfull[v] ? *reinterpret_cast<const float4*>(p.ln_w + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-                be[v] = kfull[v] ? *reinterpret_cast<const float4*>(p.ln_b + 4 * lane + 256 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = 0; v < 4; ++v) {
+                g[v] = *reinterpret_cast<const float4*>(p.ln_w + fcol[v]);
+                be[v] = *reinterpret_cast<const float4*>(p.ln_b + fcol[v]);
             }
         }
         float4 xv[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int b = wave + NW * j;
+            const int b = min(wave + NW * j, p.B - 1);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xv[j][v] = *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + fcol[v]);
+        }
+        if (row_begin < row_end) wload(0, row_begin);
+        __builtin_amdgcn_sched_barrier(0);  // all requests are in flight before the first fix-up below
+        if (p.xmode == XMODE_LAYERNORM) {
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                xv[j][v] = (kfull[v] && b < p.B && b < NB) ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + 4 * lane + 256 * v)
-                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!kfull[v]) g[v] = be[v] = make_float4(0.f, 0.f, 0.f, 0.f);  // gamma = beta = 0 outside the row: padding lanes stay 0
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (!kfull[v] || wave + NW * j >= p.B) xv[j][v] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int b = wave + NW * j;
@@ -168,24 +190,30 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
 #pragma unroll
             for (int v = 0; v < V; ++v)
                 xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][ks0 + 4 * lane + 256 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (p.X2 == nullptr) {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
+    } else {
+        if (p.X2 == nullptr) {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    xr[b][v] = *reinterpret_cast<const float4*>(p.X + (size_t)min(b, p.B - 1) * p.K + kcol[v]);
+        } else {  // concatenated activations [X ; X2], K/2 columns each (K/2 is a multiple of 4: a float4 never straddles)
+            const int kh = p.K >> 1;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int col = kcol[v];
+                    const float* src = col < kh ? p.X + (size_t)min(b, p.B - 1) * kh + col : p.X2 + (size_t)min(b, p.B - 1) * kh + (col - kh);
+                    xr[b][v] = *reinterpret_cast<const float4*>(src);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < V; ++v)
-                xr[b][v] = (kok[v] && b < p.B)
-                               ? *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + ks0 + 4 * lane + 256 * v)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {  // concatenated activations [X ; X2], K/2 columns each (K/2 is a multiple of 4: a float4 never straddles)
-        const int kh = p.K >> 1;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const int col = ks0 + 4 * lane + 256 * v;
-                const float* src = col < kh ? p.X + (size_t)b * kh + col : p.X2 + (size_t)b * kh + (col - kh);
-                xr[b][v] = (kok[v] && b < p.B) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+                if (!kok[v] || b >= p.B) xr[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // which (row, batch) total this lane ends up holding after the butterfly
