@@ -105,6 +105,81 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, floa
     return hipGetLastError();
 }
 
+// Epilogue shared by the two fp32 GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                              const int wc, const int l31, const int hh) {
+    // Row-dependent addressing (batch split, output row pointer) is computed once per row -- the batch index of the
+    // wave's first row by ONE wave-uniform division, the rest by carry -- and the residual / position rows of a group of
+    // four rows are loaded together before they are used: in a one-round launch nothing overlaps the epilogue, and the
+    // per-element division + load-wait-use chain it replaces cost about a quarter of the K = 1024 launches.
+    int nn[2];
+    float bv[2];
+    bool nok[2];
+    int kv_which[2] = {0, 0}, kv_h[2] = {0, 0}, kv_j[2] = {0, 0};
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+        nok[tj] = nn[tj] < p.N;
+        bv[tj] = (p.bias && nok[tj]) ? p.bias[nn[tj]] : 0.f;
+        if (p.epi == EPI_KV_HEADS) {
+            const int dkv = p.kv_heads * HEAD_DIM;
+            kv_which[tj] = nn[tj] / dkv;
+            const int r2 = nn[tj] - kv_which[tj] * dkv;
+            kv_h[tj] = r2 / HEAD_DIM;
+            kv_j[tj] = r2 - kv_h[tj] * HEAD_DIM;
+        }
+    }
+    const int mw = m0 + wr * 64;                       // first row of this wave (wave-uniform)
+    const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            long long offs[4];
+            int crs[4];
+            bool mok[4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int o = ti * 32 + ri + 8 * rq + 4 * hh;
+                mok[ri] = mw + o < p.M;
+                int cb = cb_w, cr = cr_w + o;
+                while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
+                crs[ri] = cr;
+                offs[ri] = p.epi == EPI_ROWMAJOR ? (long long)cb * p.c_batch_stride + (long long)cr * p.ldc
+                                                 : (long long)cb * p.kv_heads * p.kv_cap * HEAD_DIM + (long long)(cr + p.kv_seq_off) * HEAD_DIM;
+            }
+            float extra[4][2];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    extra[ri][tj] = (p.resid && mok[ri] && nok[tj]) ? p.resid[offs[ri] + nn[tj]] : 0.f;
+            float posv[4][2];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    posv[ri][tj] = (p.pos && mok[ri] && nok[tj]) ? p.pos[(long long)crs[ri] * p.N + nn[tj]] : 0.f;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    if (!(mok[ri] && nok[tj])) continue;
+                    float v = acc[ti][tj][rq * 4 + ri] + bv[tj];
+                    if (p.act) v = gelu_erf(v);
+                    v += posv[ri][tj];
+                    if (p.epi == EPI_ROWMAJOR) {
+                        p.C[offs[ri] + nn[tj]] = v + extra[ri][tj];
+                    } else {
+                        float* base = kv_which[tj] ? p.C2 : p.C;
+                        base[offs[ri] + (long long)kv_h[tj] * p.kv_cap * HEAD_DIM + kv_j[tj]] = v;
+                    }
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
 // 128x128 block tile, 4 waves in a 2x2 grid, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32 (exact fp32,
 // 64 FLOP/clk/SIMD), K-step 16 (32 selectable).  A and W tiles are staged global -> registers -> LDS (rows padded by 4 floats so the
@@ -209,76 +284,100 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    // Row-dependent addressing (batch split, output row pointer) is computed once per row -- the batch index of the
-    // wave's first row by ONE wave-uniform division, the rest by carry -- and the residual / position rows of a group of
-    // four rows are loaded together before they are used: in a one-round launch nothing overlaps the epilogue, and the
-    // per-element division + load-wait-use chain it replaces cost about a quarter of the K = 1024 launches.
-    int nn[2];
-    float bv[2];
-    bool nok[2];
-    int kv_which[2] = {0, 0}, kv_h[2] = {0, 0}, kv_j[2] = {0, 0};
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
-        nok[tj] = nn[tj] < p.N;
-        bv[tj] = (p.bias && nok[tj]) ? p.bias[nn[tj]] : 0.f;
-        if (p.epi == EPI_KV_HEADS) {
-            const int dkv = p.kv_heads * HEAD_DIM;
-            kv_which[tj] = nn[tj] / dkv;
-            const int r2 = nn[tj] - kv_which[tj] * dkv;
-            kv_h[tj] = r2 / HEAD_DIM;
-            kv_j[tj] = r2 - kv_h[tj] * HEAD_DIM;
-        }
+    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+}
+
+// The same GEMM with the tiles staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPR staging, no ds_write),
+// used when K is a multiple of 16.  One wave instruction writes 1 KiB linearly (wave-uniform base + lane * 16 B), so the LDS
+// tile is UNPADDED, [row][4 chunks of 4 floats], and bank conflicts of the fragment reads are avoided by an XOR swizzle
+// applied on both sides (cdna guide §5.4 rule 21): the lane that fills LDS chunk position `pos` of row r fetches global
+// chunk pos ^ ((r >> 2) & 3); a fragment read of chunk c of row r reads position c ^ ((r >> 2) & 3).  Rows 4a+b, a,b < 4,
+// then cover all 16 sixteen-byte bank groups for every c.  Two 16 KiB stages; the DMA of tile kt+1 is issued right
+// after the barrier that opens tile kt and lands while tile kt is multiplied.
+__global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p) {
+    constexpr int BK = 16;
+    __shared__ __attribute__((aligned(1024))) float smem[2][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware tile order (see gemm_f32_kernel)
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mw = m0 + wr * 64;                       // first row of this wave (wave-uniform)
-    const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * GBM, n0 = bx * GBN;
+
+    // DMA map: wave w, pass j fills rows j*64 + w*16 .. +15; lane -> (row lane >> 2, chunk position lane & 3)
+    const int r_local = lane >> 2, csrc = (lane & 3) ^ ((r_local >> 2) & 3);
+    const float* aptr[2];
+    const float* wptr[2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int j = 0; j < 2; ++j) {
+        const int row = j * 64 + wave * 16 + r_local;
+        const int m = min(m0 + row, p.M - 1);
+        const int bb = m / p.a_rows_per_batch;
+        aptr[j] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 4;
+        const int n = min(n0 + row, p.N - 1);
+        wptr[j] = p.W + (long long)n * p.K + csrc * 4;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const int stage, const int kt) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            long long offs[4];
-            int crs[4];
-            bool mok[4];
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+        }
+    };
+
+    // fragment reads: rows wr*64 + l31 (+32) of A, wc*64 + l31 (+32) of W; chunk 2q + hh at position (2q + hh) ^ swz
+    const int swz = (l31 >> 2) & 3;
+    const int ra = (wr * 64 + l31) * BK, rb = (wc * 64 + l31) * BK;
+    const int po0 = ((0 + hh) ^ swz) * 4, po1 = ((2 + hh) ^ swz) * 4;
+
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int o = ti * 32 + ri + 8 * rq + 4 * hh;
-                mok[ri] = mw + o < p.M;
-                int cb = cb_w, cr = cr_w + o;
-                while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
-                crs[ri] = cr;
-                offs[ri] = p.epi == EPI_ROWMAJOR ? (long long)cb * p.c_batch_stride + (long long)cr * p.ldc
-                                                 : (long long)cb * p.kv_heads * p.kv_cap * HEAD_DIM + (long long)(cr + p.kv_seq_off) * HEAD_DIM;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    const int nk = p.K / BK;
+    dma(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
+        __syncthreads();                                   // ... everyone's has, and nobody still reads the other stage
+        if (kt + 1 < nk) dma(cur ^ 1, kt + 1);
+        const float* As = &smem[cur][0][0];
+        const float* Ws = &smem[cur][1][0];
+        // (pinning all eight fragment reads above the first MFMA with sched_barrier measured 7 % SLOWER: the compiler's own
+        //  interleaving of the second four reads with the first sixteen MFMAs is the better schedule)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int po = q ? po1 : po0;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ra + po);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
             }
-            float extra[4][2];
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-                    extra[ri][tj] = (p.resid && mok[ri] && nok[tj]) ? p.resid[offs[ri] + nn[tj]] : 0.f;
-            float posv[4][2];
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-                    posv[ri][tj] = (p.pos && mok[ri] && nok[tj]) ? p.pos[(long long)crs[ri] * p.N + nn[tj]] : 0.f;
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) {
-                    if (!(mok[ri] && nok[tj])) continue;
-                    float v = acc[ti][tj][rq * 4 + ri] + bv[tj];
-                    if (p.act) v = gelu_erf(v);
-                    v += posv[ri][tj];
-                    if (p.epi == EPI_ROWMAJOR) {
-                        p.C[offs[ri] + nn[tj]] = v + extra[ri][tj];
-                    } else {
-                        float* base = kv_which[tj] ? p.C2 : p.C;
-                        base[offs[ri] + (long long)kv_h[tj] * p.kv_cap * HEAD_DIM + kv_j[tj]] = v;
-                    }
-                }
         }
     }
+    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
 }
 
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
@@ -303,7 +402,10 @@ hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
     const int tiles = nbx * nby;
     int bk = 16;
     if (force_bk == 16 || force_bk == 32) bk = force_bk;
-    if (bk == 16) hipLaunchKernelGGL(gemm_f32_kernel<16>, dim3(tiles), dim3(256), gemm_smem_bytes<16>(), s, p);
+    static const bool no_dma = getenv("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
+    if (!no_dma && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
+        hipLaunchKernelGGL(gemm_f32_dma_kernel, dim3(tiles), dim3(256), 0, s, p);
+    else if (bk == 16) hipLaunchKernelGGL(gemm_f32_kernel<16>, dim3(tiles), dim3(256), gemm_smem_bytes<16>(), s, p);
     else hipLaunchKernelGGL(gemm_f32_kernel<32>, dim3(tiles), dim3(256), gemm_smem_bytes<32>(), s, p);
     return hipGetLastError();
 }
