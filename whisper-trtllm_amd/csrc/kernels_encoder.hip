@@ -356,7 +356,6 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
         __syncthreads();                                   // ... everyone's has, and nobody still reads the other stage
-        if (kt + 1 < nk) dma(cur ^ 1, kt + 1);
         const float* As = &smem[cur][0][0];
         const float* Ws = &smem[cur][1][0];
         // (pinning all eight fragment reads above the first MFMA with sched_barrier measured 7 % SLOWER: the compiler's own
@@ -368,6 +367,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
+            if (q == 0 && kt + 1 < nk) dma(cur ^ 1, kt + 1);  // after the first fragment reads are on their way
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
