@@ -35,6 +35,12 @@ int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vc
 int wt_dbg_decode_attention_folded(const float* u, const float* kcache, const float* vcache, float* part, int* cnt, float* out,
                                    const float* ln_h, const float* ln_r, const float* ln_t, int B, int H, int s_cap, int len,
                                    int n_split, void* stream);
+/* decode attention with the split merge DEFERRED into the consumer: dec_attn_kernel leaves its n_split >= 2 partials in
+ * `part` [B][H][n_split][68] and the out-projection Y = merge(part) . W^T + bias + resid ([B][H*64]) merges them while it
+ * stages its activation rows (the cross-attention -> out-projection pair of the decode step) */
+int wt_dbg_attention_then_projection(const float* q, const float* kcache, const float* vcache, float* part, const float* W,
+                                     const float* bias, const float* resid, float* Y, int B, int H, int s_cap, int len, int n_split,
+                                     void* stream);
 /* two skinny GEMMs in one launch: Ya = Xa . Wa^T + bias_a + resid_a ([B][Na], K = Ka) and
  * Yb = [Xb ; Xb2] . Wb^T + bias_b ([B][Nb], K = Kb = 2 * columns of Xb) */
 int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka,

@@ -241,3 +241,31 @@ def test_skinny_pair(lib, B, d):
     assert (h1.cpu().double() - ref1).abs().max().item() < 2e-5
     assert (uo.cpu().double() - ref2).abs().max().item() < 2e-5
     assert torch.equal(hd.cpu(), h)   # the residual input is read-only (h1 goes to the other buffer)
+
+
+@pytest.mark.parametrize("B,H,cap,length,n_split", [(8, 16, 1500, 1500, 2), (3, 6, 1500, 1500, 2), (1, 8, 1500, 1500, 16), (2, 12, 200, 199, 5),
+                                                    (16, 16, 1500, 1500, 2), (5, 2, 96, 96, 3)])
+def test_attention_with_deferred_merge(lib, B, H, cap, length, n_split):
+    """The decode step's cross-attention -> out-projection pair: the attention kernel leaves its split partials, the GEMV merges
+    them while staging.  Against fp64 torch, and bitwise against the attention kernel's own (ticket) merge + the plain GEMV."""
+    d = 64 * H
+    q = _rand(B, d, seed=41) * 0.5
+    k, v = _rand(B, H, cap, 64, seed=42), _rand(B, H, cap, 64, seed=43)
+    W, bias, resid = _rand(d, d, seed=44, scale=d ** -0.5), _rand(d, seed=45), _rand(B, d, seed=46)
+    qd, kd, vd, Wd, bd, rd = q.cuda(), k.cuda(), v.cuda(), W.cuda(), bias.cuda(), resid.cuda()
+    part = torch.full((B, H, n_split, 68), float("nan"), device="cuda")
+    y = torch.full((B, d), float("nan"), device="cuda")
+    assert lib.wt_dbg_attention_then_projection(P(qd), P(kd), P(vd), P(part), P(Wd), P(bd), P(rd), P(y), B, H, cap, length, n_split, _stream()) == 0
+    # the two-kernel reference path of the same library: attention with its own merge, then the plain GEMV
+    cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+    att = torch.full((B, d), float("nan"), device="cuda")
+    y2 = torch.full((B, d), float("nan"), device="cuda")
+    part2 = torch.full((B, H, n_split, 68), float("nan"), device="cuda")
+    assert lib.wt_dbg_decode_attention(P(qd), P(kd), P(vd), P(part2), P(cnt), P(att), B, H, cap, length, n_split, _stream()) == 0
+    assert lib.wt_dbg_skinny(P(att), None, None, P(Wd), P(bd), P(rd), P(y2), B, d, d, 4, 0, 1.0, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), y2.cpu())
+    qh = q.double().view(B, H, 1, 64)
+    a64 = (torch.softmax(qh @ k.double()[:, :, :length].transpose(-1, -2), -1) @ v.double()[:, :, :length]).reshape(B, d)
+    ref = resid.double() + a64 @ W.double().T + bias.double()
+    assert (y.cpu().double() - ref).abs().max().item() < 3e-5

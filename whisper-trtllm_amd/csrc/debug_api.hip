@@ -50,6 +50,22 @@ extern "C" int wt_dbg_decode_attention_folded(const float* u, const float* kcach
     a.fixed_len = len; a.ln_h = ln_h; a.ln_r = ln_r; a.ln_t = ln_t;
     return rc_of(launch_dec_attn(a, (hipStream_t)stream));
 }
+extern "C" int wt_dbg_attention_then_projection(const float* q, const float* kcache, const float* vcache, float* part, const float* W,
+                                               const float* bias, const float* resid, float* Y, int B, int H, int s_cap, int len,
+                                               int n_split, void* stream) {
+    if (len < 1 || len > s_cap || n_split < 2 || n_split > 16 || H * 64 > 1024) return -22;
+    DecAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
+    a.fixed_len = len; a.defer_merge = 1;
+    int rc = rc_of(launch_dec_attn(a, (hipStream_t)stream));
+    if (rc) return rc;
+    SkinnyParams k;
+    memset(&k, 0, sizeof k);
+    k.parts = part; k.parts_nsplit = n_split; k.parts_H = H; k.W = W; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B; k.N = H * 64;
+    k.K = H * 64; k.q_scale = 1.f; k.w_nt = 1;
+    return rc_of(launch_skinny(k, (hipStream_t)stream));
+}
 extern "C" int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka,
                                   const float* Xb, const float* Xb2, const float* Wb, const float* bias_b, float* Yb, int Nb, int Kb,
                                   int B, void* stream) {

@@ -117,7 +117,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     // rows (L2 / Infinity-Cache hits, ~1 us) go out BEFORE the first W rows (HBM, 2+ us under the burst) and the
     // LayerNorm + staging + barrier run while the weights are still in flight; measured with in-kernel timestamps the
     // other order left the whole prologue behind the arrival of the weights.
-    const bool staged = p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2));
+    const bool staged = p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2) && !p.parts);
     if (!staged && row_begin < row_end) wload(0, row_begin);
     if (staged) {
         // every wave of the block needs (a slice of) the same NB whole rows: stage them once per block through LDS.
@@ -138,14 +138,71 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             }
         }
         float4 xv[2][4];
+        if (p.parts == nullptr) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int b = min(wave + NW * j, p.B - 1);
+            for (int j = 0; j < 2; ++j) {
+                const int b = min(wave + NW * j, p.B - 1);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xv[j][v] = *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + fcol[v]);
+                for (int v = 0; v < 4; ++v) xv[j][v] = *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + fcol[v]);
+            }
+            if (row_begin < row_end) wload(0, row_begin);
+            __builtin_amdgcn_sched_barrier(0);  // all requests are in flight before the first fix-up below
+        } else {
+            // the activation row is the merge of the attention kernel's split partials (deferred from its tail: no ticket, no
+            // write-through stores there).  Same operations in the same order as dec_attn_kernel's own merge -> same bits.
+            const int ns = p.parts_nsplit;
+            if (ns == 2) {  // the cross-attention case at B >= 8: both partials of all 8 chunks requested before the first use
+                float4 o0[2][4], o1[2][4];
+                float m0[2][4], m1[2][4], l0[2][4], l1[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int b = min(wave + NW * j, p.B - 1);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float* base = p.parts + ((size_t)b * p.parts_H + (fcol[v] >> 6)) * 2 * PART_STRIDE;
+                        o0[j][v] = *reinterpret_cast<const float4*>(base + (fcol[v] & 63));
+                        o1[j][v] = *reinterpret_cast<const float4*>(base + PART_STRIDE + (fcol[v] & 63));
+                        m0[j][v] = base[64]; l0[j][v] = base[65];
+                        m1[j][v] = base[PART_STRIDE + 64]; l1[j][v] = base[PART_STRIDE + 65];
+                    }
+                }
+                if (row_begin < row_end) wload(0, row_begin);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float Mg = fmaxf(fmaxf(-INFINITY, m0[j][v]), m1[j][v]);
+                        const float w0 = __expf(m0[j][v] - Mg), w1 = __expf(m1[j][v] - Mg);
+                        const float Lg = fmaf(w1, l1[j][v], fmaf(w0, l0[j][v], 0.f));
+                        xv[j][v].x = fmaf(w1, o1[j][v].x, fmaf(w0, o0[j][v].x, 0.f)) / Lg;
+                        xv[j][v].y = fmaf(w1, o1[j][v].y, fmaf(w0, o0[j][v].y, 0.f)) / Lg;
+                        xv[j][v].z = fmaf(w1, o1[j][v].z, fmaf(w0, o0[j][v].z, 0.f)) / Lg;
+                        xv[j][v].w = fmaf(w1, o1[j][v].w, fmaf(w0, o0[j][v].w, 0.f)) / Lg;
+                    }
+            } else {
+                if (row_begin < row_end) wload(0, row_begin);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int b = min(wave + NW * j, p.B - 1);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float* base = p.parts + ((size_t)b * p.parts_H + (fcol[v] >> 6)) * ns * PART_STRIDE;
+                        float Mg = -INFINITY;
+                        for (int s = 0; s < ns; ++s) Mg = fmaxf(Mg, base[s * PART_STRIDE + 64]);
+                        float4 og = make_float4(0.f, 0.f, 0.f, 0.f);
+                        float Lg = 0.f;
+                        for (int s = 0; s < ns; ++s) {
+                            const float w = __expf(base[s * PART_STRIDE + 64] - Mg);
+                            const float4 os = *reinterpret_cast<const float4*>(base + s * PART_STRIDE + (fcol[v] & 63));
+                            og.x = fmaf(w, os.x, og.x); og.y = fmaf(w, os.y, og.y); og.z = fmaf(w, os.z, og.z); og.w = fmaf(w, os.w, og.w);
+                            Lg = fmaf(w, base[s * PART_STRIDE + 65], Lg);
+                        }
+                        xv[j][v] = make_float4(og.x / Lg, og.y / Lg, og.z / Lg, og.w / Lg);
+                    }
+                }
+            }
         }
-        if (row_begin < row_end) wload(0, row_begin);
-        __builtin_amdgcn_sched_barrier(0);  // all requests are in flight before the first fix-up below
         if (p.xmode == XMODE_LAYERNORM) {
 #pragma unroll
             for (int v = 0; v < 4; ++v)
@@ -337,6 +394,7 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
     if (KS & 3) return hipErrorInvalidValue;
     if (p.K > 1024 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;  // LayerNorm needs whole rows staged in LDS
     if (p.X2 && (p.xmode != XMODE_PLAIN || (p.K & 7))) return hipErrorInvalidValue;
+    if (p.parts && (p.K > 1024 || p.K != p.parts_H * 64 || p.parts_nsplit < 1 || p.parts_nsplit > 16 || p.X2)) return hipErrorInvalidValue;
     const int G = NW / nsplit;
     const int target_groups = 2048 / nsplit;  // 256 CUs x 8 waves
     int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
@@ -531,6 +589,14 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     }
     float* pbase = p.part + ((size_t)b * p.H + h) * p.n_split * PART_STRIDE;
     float* pp = pbase + split * PART_STRIDE;
+    if (p.defer_merge) {  // the consumer GEMV merges the splits while it stages its activations (kernel boundary = visibility)
+        pp[lane] = o;
+        if (lane == 0) {
+            pp[64] = M;
+            pp[65] = L;
+        }
+        return;
+    }
     // publish (cdna guide §6 G16, write-through form): every payload word is stored sc1 by THIS wave, the wave
     // drains its stores, then one lane takes an arrival ticket; the last arriver reads every word with sc1 loads.
     __hip_atomic_store(pp + lane, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

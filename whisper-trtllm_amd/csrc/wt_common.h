@@ -55,11 +55,15 @@ struct GemmParams {
 };
 enum { EPI_ROWMAJOR = 0, EPI_KV_HEADS = 1 };
 
+constexpr int PART_STRIDE = 68;  // attention split partial: o[64], m, l, 2 pad floats
+
 // ---- decode-step skinny GEMM:  y[b][n] = epi( sum_k X(b)[k] * W[n][k] + bias[n] ),  b < NB <= 8 -----------
 enum { XMODE_PLAIN = 0, XMODE_LAYERNORM = 1 };
 enum { YMODE_PLAIN = 0, YMODE_QKV_APPEND = 1 };
 struct SkinnyParams {
     const float* X;        // [B][K]  (with X2: [B][K/2], columns [0, K/2))
+    const float* parts;    // optional: X is the MERGE of attention split partials [B][parts_H][parts_nsplit][PART_STRIDE] (o[64], m, l)
+                           //           written by dec_attn_kernel with defer_merge (K = parts_H * 64, LDS-staged path only)
     const float* X2;       // optional second activation [B][K/2] for columns [K/2, K): y = W . [X ; X2]  (x_direct path)
     const float* ln_w;     // LAYERNORM gamma/beta [K]
     const float* ln_b;
@@ -78,8 +82,8 @@ struct SkinnyParams {
     int ymode;
     int d_model, s_cap;    // QKV_APPEND
     float q_scale;         // QKV_APPEND: multiply the q third by this (head_dim^-0.5)
+    int parts_nsplit, parts_H;
 };
-constexpr int PART_STRIDE = 68;  // o[64], m, l, 2 pad floats
 
 // ---- decode attention (query length 1), split over the key axis ---------------------------------------------
 struct DecAttnParams {
@@ -93,6 +97,7 @@ struct DecAttnParams {
     int B, H, s_cap;
     int n_split;
     int fixed_len;         // >0: number of keys (cross attention); 0: use st->self_len + 1
+    int defer_merge;       // n_split > 1: leave the split partials in `part` (plain stores, no ticket); the consumer GEMV merges them
     // folded cross-attention query: q holds u = s.Wq.diag(gamma).h1 (+ const) and the kernel finishes the
     // LayerNorm per row: q = (u - mean(h1) . ln_r) * rstd(h1) + ln_t.  ln_h == nullptr: q is used as it is.
     const float* ln_h;     // [B][d] residual stream whose LayerNorm statistics normalise q
