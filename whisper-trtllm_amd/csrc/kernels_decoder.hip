@@ -293,16 +293,16 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    float a = 0.f;
+                    // packed fp32 FMA (v_pk_fma_f32): even and odd columns accumulate in the two halves of a register pair
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    f2v a2 = f2v{0.f, 0.f};
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
                         const float4 w = wbuf[cur][r][v];
-                        a = fmaf(w.x, xr[b][v].x, a);
-                        a = fmaf(w.y, xr[b][v].y, a);
-                        a = fmaf(w.z, xr[b][v].z, a);
-                        a = fmaf(w.w, xr[b][v].w, a);
+                        a2 = __builtin_elementwise_fma(f2v{w.x, w.y}, f2v{xr[b][v].x, xr[b][v].y}, a2);
+                        a2 = __builtin_elementwise_fma(f2v{w.z, w.w}, f2v{xr[b][v].z, xr[b][v].w}, a2);
                     }
-                    acc[r][b] = a;
+                    acc[r][b] = a2[0] + a2[1];
                 }
             // butterfly stage 1 (lanes l <-> l^32): lower half-wave keeps row 0, upper half-wave row 1
             float s1[NB];
