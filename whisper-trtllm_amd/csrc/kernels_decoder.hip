@@ -112,6 +112,26 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         }
     };
     // W values of clamped (out-of-slice) lanes are multiplied by activations that ARE zeroed below, so they need no fix-up
+    // which (row, batch) total this lane ends up holding after the butterfly
+    const int rho = lane >> 4, li = lane & 15;
+    const int my_r = rho >> 1;
+    const int my_b = li + (rho & 1) * (NB / 2);
+    const bool is_out_lane = li < NB / 2;
+    // The epilogue operands of the FIRST row pair (bias, residual element, append position) are requested before anything
+    // else: loaded where they are used they were two dependent L2 round trips at the very end of every launch
+    // (in-kernel timestamps: ~0.8 us between "weights landed" and "stores issued" for 128 packed FMAs and a butterfly).
+    float bias_pf = 0.f, resid_pf = 0.f;
+    int self_len_pf = 0;
+    {
+        const int n_pf = min(row_begin + my_r, p.N - 1), b_pf = min(my_b, p.B - 1);
+        if (p.bias) bias_pf = p.bias[n_pf];
+        if (p.ymode == YMODE_PLAIN) {
+            if (p.resid) resid_pf = p.resid[(size_t)b_pf * p.N + n_pf];
+        } else {
+            self_len_pf = p.st->self_len;
+        }
+    }
+
     // ---- activation slice -> registers -------------------------------------------------------------------
     // vmcnt retires in issue order, so whatever is requested first is waited for first: with LDS staging the activation
     // rows (L2 / Infinity-Cache hits, ~1 us) go out BEFORE the first W rows (HBM, 2+ us under the burst) and the
@@ -273,12 +293,6 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 if (!kok[v] || b >= p.B) xr[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // which (row, batch) total this lane ends up holding after the butterfly
-    const int rho = lane >> 4, li = lane & 15;
-    const int my_r = rho >> 1;
-    const int my_b = li + (rho & 1) * (NB / 2);
-    const bool is_out_lane = li < NB / 2;
-
     const int niter = (rows_per_group + 1) / 2;  // identical for every wave of the block (barriers below)
     // one iteration = two W rows; `cur` (static) is the register buffer holding them, the other one is prefetched
     auto body = [&](auto cur_c, const int it) {
@@ -338,12 +352,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         }
         const int n = row + my_r;
         if (do_epi && n < row_end && my_b < p.B) {
-            float v = total + (p.bias ? p.bias[n] : 0.f);
+            float v = total + (it == 0 ? bias_pf : (p.bias ? p.bias[n] : 0.f));
             if (p.ymode == YMODE_PLAIN) {
                 v *= p.q_scale;
                 if (p.act) v = gelu_erf_d(v);
                 const size_t off = (size_t)my_b * p.N + n;
-                if (p.resid) v += p.resid[off];
+                if (p.resid) v += it == 0 ? resid_pf : p.resid[off];
                 p.Y[off] = v;
             } else {  // fused q|k|v projection: q (scaled) -> Y, k/v rows appended in place at index self_len
                 const int third = n / p.d_model, nn = n - third * p.d_model;
@@ -352,7 +366,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 } else {
                     const int h = nn >> 6, j = nn & 63, H = p.d_model >> 6;
                     float* cache = third == 1 ? p.kcache : p.vcache;
-                    cache[(((size_t)my_b * H + h) * p.s_cap + p.st->self_len) * HEAD_DIM + j] = v;
+                    cache[(((size_t)my_b * H + h) * p.s_cap + self_len_pf) * HEAD_DIM + j] = v;
                 }
             }
         }
