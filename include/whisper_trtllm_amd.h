@@ -75,7 +75,8 @@ typedef struct {
     int32_t n_mels, max_source_positions, max_target_positions, vocab_size;
 } wt_engine_info;
 
-/* (1) replaces Session.from_serialized_engine (session.py:54): parse the blob, upload weights to `device`. */
+/* (1) replaces Session.from_serialized_engine (session.py:54): parse the blob, upload weights to `device`.
+ * Blobs are versioned (engine_pack.py VERSION); a blob written by another version is refused with WT_E_UNSUPPORTED. */
 int wt_engine_open(const void* blob, size_t nbytes, int device, wt_engine** out);
 /* (2) engine teardown (TensorRT: ICudaEngine/IExecutionContext destructors). */
 void wt_engine_close(wt_engine* e);
@@ -115,7 +116,8 @@ typedef struct {
     float* logits_trace;              /* optional device buffer f32 [batch, max_length-1, V] of raw logits, or NULL */
 } wt_greedy_params;
 
-/* (6) start a greedy decode of `batch` utterances: project the encoder memory f32 [batch,S,d] into the
+/* (6) start a greedy decode of `batch` utterances (1 <= batch <= 16 per call, WT_E_UNSUPPORTED above; shard larger
+ * batches over calls or GPUs): project the encoder memory f32 [batch,S,d] into the
  * resident cross-KV cache, reset the self-KV cache and the id buffer to [[decoder_start_token_id]]*batch.
  * Replaces greedy_search() step 0 (run.py:171-197 with past_key_values=None).  Asynchronous. */
 int wt_decoder_begin(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p, void* stream);
