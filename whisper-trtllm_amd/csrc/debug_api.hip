@@ -53,7 +53,7 @@ extern "C" int wt_dbg_decode_attention_folded(const float* u, const float* kcach
 extern "C" int wt_dbg_attention_then_projection(const float* q, const float* kcache, const float* vcache, float* part, const float* W,
                                                const float* bias, const float* resid, float* Y, int B, int H, int s_cap, int len,
                                                int n_split, void* stream) {
-    if (len < 1 || len > s_cap || n_split < 2 || n_split > 16 || H * 64 > 1024) return -22;
+    if (len < 1 || len > s_cap || n_split != 2 || H * 64 > 1024) return -22;
     DecAttnParams a;
     memset(&a, 0, sizeof a);
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;

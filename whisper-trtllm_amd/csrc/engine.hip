@@ -546,7 +546,8 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         memset(&a, 0, sizeof a);
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
         a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t;
-        a.defer_merge = defer && io.nsplit_cross > 1;  // the out-projection below merges the split partials while staging them
+        a.defer_merge = defer && io.nsplit_cross == 2;  // the out-projection below merges the two split partials while staging them
+                                                        // (more splits, i.e. batch < 8: the attention kernel merges its own, by ticket)
         {
             hipEvent_t ta, tb;
             timer_begin(e, e->t_cross, s, &ta, &tb);
@@ -556,7 +557,7 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         memset(&k, 0, sizeof k);
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = h1;
         k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
-        if (defer && io.nsplit_cross > 1) { k.parts = e->part; k.parts_nsplit = io.nsplit_cross; k.parts_H = H; }
+        if (defer && io.nsplit_cross == 2) { k.parts = e->part; k.parts_nsplit = io.nsplit_cross; k.parts_H = H; }
         LAUNCH(launch_skinny(k, s));
         // --- FFN (model.py:363-367)
         memset(&k, 0, sizeof k);
@@ -640,7 +641,7 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     // measured (tools/microbench.py, medium.en B=8): self attention is fastest unsplit at every length <= 448;
     // cross attention (1500 keys) with ~one block per CU
     e->nsplit_self = 1;
-    e->nsplit_cross = pick_splits(B, e->H, e->S);
+    e->nsplit_cross = getenv("WT_NSPLIT_CROSS") ? atoi(getenv("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
     LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s));  // input of step 0
     rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, s);
@@ -897,7 +898,7 @@ extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* a
         a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = e->B; a.H = e->H; a.s_cap = e->S;
         a.n_split = e->nsplit_cross; a.fixed_len = e->S;
         a.ln_h = e->dh2; a.ln_r = e->dec_layers[i].fold_r; a.ln_t = e->dec_layers[i].fold_t;  // as in the decode step
-        a.defer_merge = e->nsplit_cross > 1;
+        a.defer_merge = e->nsplit_cross == 2 && getenv("WT_NO_DEFER_MERGE") == nullptr;
         le = launch_dec_attn(a, e->own_stream);
     }
     hipError_t ce = hipStreamEndCapture(e->own_stream, &g);

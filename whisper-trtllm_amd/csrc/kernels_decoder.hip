@@ -170,58 +170,35 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         } else {
             // the activation row is the merge of the attention kernel's split partials (deferred from its tail: no ticket, no
             // write-through stores there).  Same operations in the same order as dec_attn_kernel's own merge -> same bits.
-            const int ns = p.parts_nsplit;
-            if (ns == 2) {  // the cross-attention case at B >= 8: both partials of all 8 chunks requested before the first use
-                float4 o0[2][4], o1[2][4];
-                float m0[2][4], m1[2][4], l0[2][4], l1[2][4];
+            // exactly two splits (launch_skinny checks): both partials of all 8 chunks are requested before the first use
+            float4 o0[2][4], o1[2][4];
+            float m0[2][4], m1[2][4], l0[2][4], l1[2][4];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int b = min(wave + NW * j, p.B - 1);
+            for (int j = 0; j < 2; ++j) {
+                const int b = min(wave + NW * j, p.B - 1);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const float* base = p.parts + ((size_t)b * p.parts_H + (fcol[v] >> 6)) * 2 * PART_STRIDE;
-                        o0[j][v] = *reinterpret_cast<const float4*>(base + (fcol[v] & 63));
-                        o1[j][v] = *reinterpret_cast<const float4*>(base + PART_STRIDE + (fcol[v] & 63));
-                        m0[j][v] = base[64]; l0[j][v] = base[65];
-                        m1[j][v] = base[PART_STRIDE + 64]; l1[j][v] = base[PART_STRIDE + 65];
-                    }
-                }
-                if (row_begin < row_end) wload(0, row_begin);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const float Mg = fmaxf(fmaxf(-INFINITY, m0[j][v]), m1[j][v]);
-                        const float w0 = __expf(m0[j][v] - Mg), w1 = __expf(m1[j][v] - Mg);
-                        const float Lg = fmaf(w1, l1[j][v], fmaf(w0, l0[j][v], 0.f));
-                        xv[j][v].x = fmaf(w1, o1[j][v].x, fmaf(w0, o0[j][v].x, 0.f)) / Lg;
-                        xv[j][v].y = fmaf(w1, o1[j][v].y, fmaf(w0, o0[j][v].y, 0.f)) / Lg;
-                        xv[j][v].z = fmaf(w1, o1[j][v].z, fmaf(w0, o0[j][v].z, 0.f)) / Lg;
-                        xv[j][v].w = fmaf(w1, o1[j][v].w, fmaf(w0, o0[j][v].w, 0.f)) / Lg;
-                    }
-            } else {
-                if (row_begin < row_end) wload(0, row_begin);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int b = min(wave + NW * j, p.B - 1);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const float* base = p.parts + ((size_t)b * p.parts_H + (fcol[v] >> 6)) * ns * PART_STRIDE;
-                        float Mg = -INFINITY;
-                        for (int s = 0; s < ns; ++s) Mg = fmaxf(Mg, base[s * PART_STRIDE + 64]);
-                        float4 og = make_float4(0.f, 0.f, 0.f, 0.f);
-                        float Lg = 0.f;
-                        for (int s = 0; s < ns; ++s) {
-                            const float w = __expf(base[s * PART_STRIDE + 64] - Mg);
-                            const float4 os = *reinterpret_cast<const float4*>(base + s * PART_STRIDE + (fcol[v] & 63));
-                            og.x = fmaf(w, os.x, og.x); og.y = fmaf(w, os.y, og.y); og.z = fmaf(w, os.z, og.z); og.w = fmaf(w, os.w, og.w);
-                            Lg = fmaf(w, base[s * PART_STRIDE + 65], Lg);
-                        }
-                        xv[j][v] = make_float4(og.x / Lg, og.y / Lg, og.z / Lg, og.w / Lg);
-                    }
+                for (int v = 0; v < 4; ++v) {
+                    const float* base = p.parts + ((size_t)b * p.parts_H + (fcol[v] >> 6)) * 2 * PART_STRIDE;
+                    o0[j][v] = *reinterpret_cast<const float4*>(base + (fcol[v] & 63));
+                    o1[j][v] = *reinterpret_cast<const float4*>(base + PART_STRIDE + (fcol[v] & 63));
+                    m0[j][v] = base[64]; l0[j][v] = base[65];
+                    m1[j][v] = base[PART_STRIDE + 64]; l1[j][v] = base[PART_STRIDE + 65];
                 }
             }
+            if (row_begin < row_end) wload(0, row_begin);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float Mg = fmaxf(fmaxf(-INFINITY, m0[j][v]), m1[j][v]);
+                    const float w0 = __expf(m0[j][v] - Mg), w1 = __expf(m1[j][v] - Mg);
+                    const float Lg = fmaf(w1, l1[j][v], fmaf(w0, l0[j][v], 0.f));
+                    xv[j][v].x = fmaf(w1, o1[j][v].x, fmaf(w0, o0[j][v].x, 0.f)) / Lg;
+                    xv[j][v].y = fmaf(w1, o1[j][v].y, fmaf(w0, o0[j][v].y, 0.f)) / Lg;
+                    xv[j][v].z = fmaf(w1, o1[j][v].z, fmaf(w0, o0[j][v].z, 0.f)) / Lg;
+                    xv[j][v].w = fmaf(w1, o1[j][v].w, fmaf(w0, o0[j][v].w, 0.f)) / Lg;
+                }
         }
         if (p.xmode == XMODE_LAYERNORM) {
 #pragma unroll
@@ -408,7 +385,7 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
     if (KS & 3) return hipErrorInvalidValue;
     if (p.K > 1024 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;  // LayerNorm needs whole rows staged in LDS
     if (p.X2 && (p.xmode != XMODE_PLAIN || (p.K & 7))) return hipErrorInvalidValue;
-    if (p.parts && (p.K > 1024 || p.K != p.parts_H * 64 || p.parts_nsplit < 1 || p.parts_nsplit > 16 || p.X2)) return hipErrorInvalidValue;
+    if (p.parts && (p.K > 1024 || p.K != p.parts_H * 64 || p.parts_nsplit != 2 || p.X2)) return hipErrorInvalidValue;
     const int G = NW / nsplit;
     // row groups (waves x K-splits) per launch: measured per decode step at medium.en B = 8 -- 512: 1.64 ms, 768: 1.53, 1024: 1.475,
     // 1280: 1.478, 1536: 1.49, 2048: 1.51, 3072: 1.51.  1024 = one 4-wave block per CU, each wave streaming two row pairs with
