@@ -390,8 +390,9 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
     // row groups (waves x K-splits) per launch: measured per decode step at medium.en B = 8 -- 512: 1.64 ms, 768: 1.53, 1024: 1.475,
     // 1280: 1.478, 1536: 1.49, 2048: 1.51, 3072: 1.51.  1024 = one 4-wave block per CU, each wave streaming two row pairs with
     // the second pair prefetched behind the first (A/B knob: WT_SKINNY_TARGET)
-    // (the 16-row template keeps 2048: batch 16 measured 424 audio-s/s with 2048 and 398 with 1024)
-    static const int tg_total = getenv("WT_SKINNY_TARGET") ? atoi(getenv("WT_SKINNY_TARGET")) : (NB == 16 ? 2048 : 1024);
+    // (only the 8-row template: batch 16 measured 424 audio-s/s with 2048 and 398 with 1024; batch 1 / 2 / 4: 1.07 / 1.11 / 1.24 ms
+    //  per step with 2048 and 1.09 / 1.12 / 1.27 with 1024; batch 6: 1.44 vs 1.41)
+    static const int tg_total = getenv("WT_SKINNY_TARGET") ? atoi(getenv("WT_SKINNY_TARGET")) : (NB == 8 ? 1024 : 2048);
     const int target_groups = tg_total / nsplit;
     int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
     if (rows_per_group < 2) rows_per_group = 2;
