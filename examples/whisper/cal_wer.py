@@ -2,7 +2,7 @@
 """WER on a `librispeech.cache` of (log-mel [80,3000], text) pairs — the reference's examples/whisper/cal_wer.py flow
 (:249-287) on the batched fast path.  Needs real `whisper-*.en` engines and the cache produced by the reference's
 get_LibriSpeech.py; neither exists on the build/GPU boxes, so this script is exercised only by its unit-tested parts
-(tokenizer decode and WER: tests/test_text.py).
+(tokenizer decode, English normaliser and WER: tests/test_text.py).
 
 The cache is a pickle (as in the reference): only load files you created yourself."""
 import argparse
@@ -14,7 +14,8 @@ import torch
 from _common import ROOT  # noqa: F401
 
 import whisper_trtllm_amd as tensorrt_llm
-from whisper_trtllm_amd.text import WhisperTokenDecoder, basic_normalize, word_error_rate
+from whisper_trtllm_amd.english import EnglishTextNormalizer
+from whisper_trtllm_amd.text import WhisperTokenDecoder, word_error_rate
 
 
 def parse_arguments():
@@ -28,14 +29,11 @@ def parse_arguments():
 
 
 def get_normalizer(whisper_dir):
-    """The reference normalises with whisper's EnglishTextNormalizer; use the `transformers` one when it is installed and
-    the checkpoint ships its spelling table, else the basic normaliser (WER then differs slightly from the README's)."""
-    try:
-        import json
-        from transformers.models.whisper.english_normalizer import EnglishTextNormalizer
-        return EnglishTextNormalizer(json.load(open(os.path.join(whisper_dir, "normalizer.json"))))
-    except Exception:
-        return basic_normalize
+    """The reference normalises with whisper's EnglishTextNormalizer (cal_wer.py:11, 281); `whisper_trtllm_amd.english` restates
+    it.  The British->American spelling table ships with the checkpoint (normalizer.json); without it spellings are left alone."""
+    import json
+    path = os.path.join(whisper_dir, "normalizer.json")
+    return EnglishTextNormalizer(json.load(open(path, encoding="utf-8")) if os.path.exists(path) else None)
 
 
 if __name__ == "__main__":

@@ -57,3 +57,36 @@ def test_word_error_rate_properties():
 
 def test_basic_normalize():
     assert basic_normalize("  Hello, [noise] WORLD!  (laughs) It's 5 o'clock. ") == "hello world it s 5 o clock"
+
+
+def _normalizer_goldens():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "normalizer.json")
+    return json.load(open(path, encoding="utf-8"))
+
+
+def test_english_normalizer_matches_reference_goldens():
+    """Every recorded input of tests/golden/normalizer.json (951: hand-written sentences + seeded word salads over the number
+    vocabulary) through the five normaliser entry points equals what the reference's english_normalizer.py produced."""
+    from whisper_trtllm_amd.english import BasicTextNormalizer, EnglishNumberNormalizer, EnglishTextNormalizer
+    g = _normalizer_goldens()
+    fns = {"english": EnglishTextNormalizer(g["spelling_mapping"]), "english_no_spelling": EnglishTextNormalizer(),
+           "number": EnglishNumberNormalizer(), "basic": BasicTextNormalizer(), "basic_diacritics": BasicTextNormalizer(remove_diacritics=True)}
+    assert len(g["cases"]) >= 900
+    bad = []
+    for case in g["cases"]:
+        for key, fn in fns.items():
+            got = fn(case["input"].lower() if key == "number" else case["input"])
+            if got != case[key]:
+                bad.append((key, case["input"], case[key], got))
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:3]}"
+
+
+def test_english_normalizer_examples():
+    from whisper_trtllm_amd.english import EnglishTextNormalizer
+    n = EnglishTextNormalizer({"colour": "color"})
+    assert n("Mr. Brown won't pay $20 million for the colour.") == "mister brown will not pay $20000000 for the color"
+    assert n("twenty one dollars and seven cents") == "$21.07"
+    assert n("one oh one, double oh seven") == "101007"     # the comma is gone before the digits are read: one nominal number
+    assert n("She came in 274th [laughs] (really), uh, three and a half percent.") == "she came in 274th 3.5%"

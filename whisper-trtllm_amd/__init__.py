@@ -7,7 +7,7 @@ Mirrors the slice of the `tensorrt_llm` package that examples/whisper uses
 library or without a GPU raises.
 """
 from . import _dtypes as trt  # noqa: F401  `trt.float32` spelling used by the reference's run.py
-from . import audio, builder, convert, engine_pack, generation, layers, models, module, network, runtime, sharding, synthetic, text  # noqa: F401
+from . import audio, builder, convert, engine_pack, english, generation, layers, models, module, network, runtime, sharding, synthetic, text  # noqa: F401
 from .builder import Builder, BuilderConfig  # noqa: F401
 from .logger import logger  # noqa: F401
 from .models import WhisperDecoder, WhisperEncoder  # noqa: F401

@@ -75,8 +75,8 @@ class WhisperTokenDecoder:
 
 def basic_normalize(text: str) -> str:
     """Lower-case, drop bracketed/parenthesised spans, turn symbols and punctuation into spaces, collapse whitespace
-    (the behaviour of the bundled BasicTextNormalizer, english_normalizer.py:75-91; the full English normaliser with
-    number and spelling rules needs the checkpoint's normalizer.json and is taken from `transformers` when importable)."""
+    (the behaviour of the bundled BasicTextNormalizer, english_normalizer.py:75-91, plus a final strip; the full English
+    normaliser with contraction, number and spelling rules is `whisper_trtllm_amd.english.EnglishTextNormalizer`)."""
     s = text.lower()
     s = re.sub(r"[<\[][^>\]]*[>\]]", "", s)
     s = re.sub(r"\(([^)]+?)\)", "", s)
