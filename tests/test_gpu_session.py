@@ -177,3 +177,48 @@ def test_c_abi_greedy_convenience_call(wt):
     assert rc == 0, wt._lib.last_error()
     assert out_len.value == z["ids"].shape[1]
     np.testing.assert_array_equal(ids[:, :out_len.value].cpu().numpy(), z["ids"])
+
+
+def test_cal_wer_script_end_to_end(wt, tmp_path):
+    """examples/whisper/cal_wer.py as a subprocess over artefacts this test writes itself: toy engines + config.pkl, a toy byte-level
+    vocabulary, and a `librispeech.cache` of (log-mel, reference text) pairs — fast-path decode, token decode, English normaliser,
+    pooled WER.  The expected number is recomputed here from the same library calls."""
+    import json
+    import subprocess
+    from whisper_trtllm_amd.english import EnglishTextNormalizer
+    from whisper_trtllm_amd.text import WhisperTokenDecoder, _byte_decoder, word_error_rate
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    eng, ckpt = tmp_path / "eng", tmp_path / "ckpt"
+    eng.mkdir()
+    ckpt.mkdir()
+    (eng / "WhisperEncoder.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
+    (eng / "WhisperDecoder.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
+    (eng / "config.pkl").write_bytes(pickle.dumps(cfg))
+    # vocabulary: the 256 byte symbols, then " <letter><letter>" style tokens, the end-of-text token at the config's eos id
+    symbols = sorted(_byte_decoder(), key=_byte_decoder().get)
+    space = symbols[32]
+    vocab = {s: i for i, s in enumerate(symbols)}
+    letters = "etaoinshrdlucmfwyp"
+    k = 0
+    while len(vocab) < cfg["vocab_size"]:
+        tok = space + letters[k % len(letters)] + letters[(k // len(letters)) % len(letters)] + ("s" if k >= len(letters) ** 2 else "")
+        if len(vocab) == cfg["eos_token_id"]:
+            tok = "<|endoftext|>"
+        vocab.setdefault(tok, len(vocab))
+        k += 1
+    json.dump(vocab, open(ckpt / "vocab.json", "w", encoding="utf-8"), ensure_ascii=False)
+    json.dump({"colour": "color"}, open(ckpt / "normalizer.json", "w"))
+    enc = wt.WhisperEncoderEngine((eng / "WhisperEncoder.engine").read_bytes())
+    dec = wt.WhisperDecoderEngine((eng / "WhisperDecoder.engine").read_bytes(), cfg)
+    ids = dec.generate(enc(torch.from_numpy(mel).cuda())).cpu().tolist()
+    hyp = WhisperTokenDecoder.from_dir(str(ckpt)).batch_decode(ids, skip_special_tokens=True)
+    refs = [hyp[0], "twenty one colour " + hyp[1], "completely different words here"][:len(hyp)]
+    pickle.dump([(mel[i], refs[i]) for i in range(len(refs))], open(tmp_path / "librispeech.cache", "wb"))
+    norm = EnglishTextNormalizer({"colour": "color"})
+    want = word_error_rate([norm(t) for t in refs], [norm(t) for t in hyp])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "whisper", "cal_wer.py"), "--whisper", str(ckpt), "--engine_dir", str(eng),
+                          "--cache", str(tmp_path / "librispeech.cache"), "--batch", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("WER:")][-1]
+    assert abs(float(line.split()[1]) - want * 100) < 0.006, (line, want)
+    assert 0.0 < want < 10.0
