@@ -3,6 +3,7 @@ and that the C-ABI library loads and exports every symbol its headers declare (n
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -162,3 +163,46 @@ def test_utterance_sharding():
     assert sharding.batches(3, 20, 8) == [(3, 11), (11, 19), (19, 20)]
     with pytest.raises(ValueError):
         sharding.utterance_shard(8, 2, 2)
+
+
+@pytest.mark.parametrize("fmt", ["safetensors", "bin"])
+def test_build_scripts_from_a_local_hf_checkpoint_dir(tmp_path, fmt):
+    """`build_encoder.py` / `build_decoder.py --whisper <dir>` on a local HF-format checkpoint (config.json,
+    generation_config.json, model.safetensors or pytorch_model.bin with HF tensor names; `proj_out.weight` absent because it is tied).
+    The directory is written by this test from the seeded toy weights; the engines must carry exactly those tensors."""
+    import json
+    import pickle
+    import subprocess
+    import torch
+    import whisper_trtllm_amd as w
+    cfg = w.synthetic.get_config("toy")
+    weights = w.synthetic.make_weights(cfg, 5)
+    ckpt = tmp_path / "whisper-toy.en"
+    ckpt.mkdir()
+    gen_keys = ("suppress_tokens", "begin_suppress_tokens", "forced_decoder_ids", "max_length", "decoder_start_token_id", "eos_token_id", "pad_token_id")
+    json.dump({k: v for k, v in cfg.items() if k not in gen_keys}, open(ckpt / "config.json", "w"))
+    json.dump({k: cfg[k] for k in gen_keys if k in cfg}, open(ckpt / "generation_config.json", "w"))
+    sd = {k: np.ascontiguousarray(v) for k, v in weights.items() if k != "proj_out.weight"}
+    if fmt == "safetensors":
+        from safetensors.numpy import save_file
+        save_file(sd, str(ckpt / "model.safetensors"))
+    else:
+        torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, str(ckpt / "pytorch_model.bin"))
+    eng = tmp_path / "eng"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for script in ("build_encoder.py", "build_decoder.py"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "whisper", script), "--whisper", str(ckpt), "--engine_dir", str(eng)],
+                             capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+    config = pickle.loads((eng / "config.pkl").read_bytes())
+    for k in gen_keys:
+        assert config[k] == cfg[k]
+    info, t = w.engine_pack.unpack((eng / "WhisperEncoder.engine").read_bytes())
+    assert info["kind"] == w.engine_pack.KIND_ENCODER and info["d_model"] == cfg["d_model"]
+    np.testing.assert_array_equal(t["layers.0.fc1.weight"], weights["model.encoder.layers.0.fc1.weight"])
+    info, t = w.engine_pack.unpack((eng / "WhisperDecoder.engine").read_bytes())
+    assert info["kind"] == w.engine_pack.KIND_DECODER and info["tied_proj_out"] == 1 and "proj_out.weight" not in t
+    np.testing.assert_array_equal(t["embed_tokens.weight"], weights["model.decoder.embed_tokens.weight"])
+    np.testing.assert_array_equal(t["layers.1.encoder_attn.kv.weight"][:cfg["d_model"]], weights["model.decoder.layers.1.encoder_attn.k_proj.weight"])
+    # and the blob equals the one built in-process from the same weights
+    assert (eng / "WhisperDecoder.engine").read_bytes() == bytes(w.convert.build_decoder_engine(cfg, weights))
