@@ -112,3 +112,41 @@ def test_waveform_to_token_ids_end_to_end():
     if (top2[..., 0] - top2[..., 1]).min().item() > 5e-2:   # only compare ids when the oracle's choices are clear-cut
         np.testing.assert_array_equal(ids, ids_ref.numpy())
     assert ids.shape == tuple(ids_ref.shape)
+
+
+@pytest.mark.gpu
+def test_get_librispeech_script_builds_the_cache(tmp_path):
+    """examples/whisper/get_LibriSpeech.py over a LibriSpeech-style directory of .wav files this test writes: the cache holds
+    (log-mel [80, 3000], transcript) pairs whose features equal the oracle's restatement of the reference extractor."""
+    import pickle
+    import subprocess
+    import sys
+    import wave
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    root = tmp_path / "LibriSpeech" / "test-clean" / "61" / "70968"
+    root.mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    texts, waves = {}, {}
+    for k, seconds in enumerate((1.0, 2.7, 0.4)):
+        utt = f"61-70968-{k:04d}"
+        t = np.arange(int(16000 * seconds)) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * (220 + 110 * k) * t) + 0.05 * rng.standard_normal(t.size)
+        pcm = np.clip(np.round(x * 32768.0), -32768, 32767).astype("<i2")
+        with wave.open(str(root / (utt + ".wav")), "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(16000)
+            f.writeframes(pcm.tobytes())
+        texts[utt], waves[utt] = f"UTTERANCE NUMBER {k}", pcm.astype(np.float32) / 32768.0
+    (root / "61-70968.trans.txt").write_text("".join(f"{u} {t}\n" for u, t in texts.items()))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "whisper", "get_LibriSpeech.py"), "--root", str(tmp_path / "LibriSpeech"),
+                          "--out", str(tmp_path / "librispeech.cache"), "--batch", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cache = pickle.load(open(tmp_path / "librispeech.cache", "rb"))   # a file this test just produced
+    assert [t for _, t in cache] == list(texts.values())
+    for (mel, _), utt in zip(cache, texts):
+        assert mel.shape == (80, 3000) and mel.dtype == np.float32
+        ref = cpu_ref.log_mel_spectrogram(waves[utt])
+        assert np.abs(mel - ref).max() < 2e-3
