@@ -6,8 +6,8 @@ Two decode paths over the same C-ABI:
     reference's per-token `Session.run` protocol with by-value caches (run.py:57-227), batch 1;
   * fast path (default): resident in-place KV cache, on-device greedy loop, utterance batches of 8
     (`WhisperEncoderEngine` / `WhisperDecoderEngine`).
-Without a dataset/processor on the box (`--synthetic N`) the inputs are seeded synthetic 80x3000 log-mels and the
-outputs are token ids."""
+Inputs: `--audio a.wav ...` (16 kHz mono; log-mel on the GPU front-end, transcripts printed when `--whisper` is a checkpoint
+directory with vocab.json) or, without audio on the box, `--synthetic N` seeded synthetic 80x3000 log-mels (outputs are token ids)."""
 import argparse
 import os
 import pickle
@@ -35,6 +35,9 @@ def parse_arguments():
     parser.add_argument("--compare", action="store_true", help="also decode through the Session path and compare ids")
     parser.add_argument("--session", action="store_true", help="decode through the per-token Session protocol only")
     parser.add_argument("--synthetic", type=int, default=8, help="number of synthetic utterances")
+    parser.add_argument("--audio", nargs="+", default=None, help="16 kHz mono audio files to transcribe instead (log-mel by the GPU "
+                        "front-end, i.e. what hf_processor does in the reference, run.py:267); with --whisper <checkpoint dir> the ids "
+                        "are also decoded to text (vocab.json)")
     parser.add_argument("--max_length", type=int, default=None)
     return parser.parse_args()
 
@@ -115,7 +118,17 @@ if __name__ == "__main__":
     if args.max_length:
         config["max_length"] = args.max_length
     name = config.get("name", "whisper-tiny.en")
-    mels = [torch.from_numpy(tensorrt_llm.synthetic.make_mel(config, index=i, batch=1)).cuda() for i in range(args.synthetic)]
+    if args.audio:
+        import numpy as np
+        from get_LibriSpeech import N_SAMPLES, read_audio
+        frontend = tensorrt_llm.audio.LogMelFrontend()
+        wav = np.zeros((len(args.audio), N_SAMPLES), dtype=np.float32)
+        for j, path in enumerate(args.audio):
+            a = read_audio(path)[:N_SAMPLES]
+            wav[j, :len(a)] = a
+        mels = list(frontend(torch.from_numpy(wav).cuda()).split(1))
+    else:
+        mels = [torch.from_numpy(tensorrt_llm.synthetic.make_mel(config, index=i, batch=1)).cuda() for i in range(args.synthetic)]
     results = {}
     if not args.session:
         enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
@@ -144,3 +157,7 @@ if __name__ == "__main__":
         print(f"Compare Result: same [{len(a) - len(diff)}], diff [{len(diff)}]")
     for key in results:
         print(key, "ids[0][:16] =", results[key][1][0][:16])
+    if args.audio and os.path.isdir(args.whisper):   # batch_decode(predicted_ids, skip_special_tokens=True) of run.py:287
+        tok = tensorrt_llm.text.WhisperTokenDecoder.from_dir(args.whisper)
+        for path, ids in zip(args.audio, next(iter(results.values()))[1]):
+            print(f"{os.path.basename(path)}: {tok.decode(ids, skip_special_tokens=True)!r}")

@@ -179,22 +179,10 @@ def test_c_abi_greedy_convenience_call(wt):
     np.testing.assert_array_equal(ids[:, :out_len.value].cpu().numpy(), z["ids"])
 
 
-def test_cal_wer_script_end_to_end(wt, tmp_path):
-    """examples/whisper/cal_wer.py as a subprocess over artefacts this test writes itself: toy engines + config.pkl, a toy byte-level
-    vocabulary, and a `librispeech.cache` of (log-mel, reference text) pairs — fast-path decode, token decode, English normaliser,
-    pooled WER.  The expected number is recomputed here from the same library calls."""
+def _toy_vocabulary(cfg, ckpt):
+    """vocab.json for a toy config: the 256 byte symbols, then " <letter><letter>" style tokens, <|endoftext|> at the config's eos id."""
     import json
-    import subprocess
-    from whisper_trtllm_amd.english import EnglishTextNormalizer
-    from whisper_trtllm_amd.text import WhisperTokenDecoder, _byte_decoder, word_error_rate
-    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
-    eng, ckpt = tmp_path / "eng", tmp_path / "ckpt"
-    eng.mkdir()
-    ckpt.mkdir()
-    (eng / "WhisperEncoder.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
-    (eng / "WhisperDecoder.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
-    (eng / "config.pkl").write_bytes(pickle.dumps(cfg))
-    # vocabulary: the 256 byte symbols, then " <letter><letter>" style tokens, the end-of-text token at the config's eos id
+    from whisper_trtllm_amd.text import _byte_decoder
     symbols = sorted(_byte_decoder(), key=_byte_decoder().get)
     space = symbols[32]
     vocab = {s: i for i, s in enumerate(symbols)}
@@ -207,6 +195,24 @@ def test_cal_wer_script_end_to_end(wt, tmp_path):
         vocab.setdefault(tok, len(vocab))
         k += 1
     json.dump(vocab, open(ckpt / "vocab.json", "w", encoding="utf-8"), ensure_ascii=False)
+
+
+def test_cal_wer_script_end_to_end(wt, tmp_path):
+    """examples/whisper/cal_wer.py as a subprocess over artefacts this test writes itself: toy engines + config.pkl, a toy byte-level
+    vocabulary, and a `librispeech.cache` of (log-mel, reference text) pairs — fast-path decode, token decode, English normaliser,
+    pooled WER.  The expected number is recomputed here from the same library calls."""
+    import json
+    import subprocess
+    from whisper_trtllm_amd.english import EnglishTextNormalizer
+    from whisper_trtllm_amd.text import WhisperTokenDecoder, word_error_rate
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    eng, ckpt = tmp_path / "eng", tmp_path / "ckpt"
+    eng.mkdir()
+    ckpt.mkdir()
+    (eng / "WhisperEncoder.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
+    (eng / "WhisperDecoder.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
+    (eng / "config.pkl").write_bytes(pickle.dumps(cfg))
+    _toy_vocabulary(cfg, ckpt)
     json.dump({"colour": "color"}, open(ckpt / "normalizer.json", "w"))
     enc = wt.WhisperEncoderEngine((eng / "WhisperEncoder.engine").read_bytes())
     dec = wt.WhisperDecoderEngine((eng / "WhisperDecoder.engine").read_bytes(), cfg)
@@ -222,3 +228,45 @@ def test_cal_wer_script_end_to_end(wt, tmp_path):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("WER:")][-1]
     assert abs(float(line.split()[1]) - want * 100) < 0.006, (line, want)
     assert 0.0 < want < 10.0
+
+
+def test_run_py_transcribes_audio_files(wt, tmp_path):
+    """examples/whisper/run.py --audio: .wav -> GPU log-mel front-end -> engines -> ids -> text, as a subprocess over artefacts written
+    here; the expected transcripts are recomputed through the same library calls."""
+    import subprocess
+    import wave
+    from whisper_trtllm_amd.audio import LogMelFrontend
+    from whisper_trtllm_amd.text import WhisperTokenDecoder
+    cfg = wt.synthetic.get_config("toy")          # 30 s inputs (max_source_positions 1500), 512-token vocabulary
+    weights = wt.synthetic.make_weights(cfg, 9)
+    eng, ckpt = tmp_path / "eng", tmp_path / "ckpt"
+    eng.mkdir()
+    ckpt.mkdir()
+    (eng / "WhisperEncoder.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
+    (eng / "WhisperDecoder.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
+    (eng / "config.pkl").write_bytes(pickle.dumps(cfg))
+    _toy_vocabulary(cfg, ckpt)
+    rng = np.random.default_rng(11)
+    paths, waves = [], []
+    for k, seconds in enumerate((1.5, 0.8)):
+        t = np.arange(int(16000 * seconds)) / 16000.0
+        pcm = np.clip(np.round((0.4 * np.sin(2 * np.pi * (300 + 170 * k) * t) + 0.03 * rng.standard_normal(t.size)) * 32768.0), -32768, 32767).astype("<i2")
+        path = tmp_path / f"clip{k}.wav"
+        with wave.open(str(path), "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(16000)
+            f.writeframes(pcm.tobytes())
+        paths.append(str(path))
+        w30 = np.zeros(480000, dtype=np.float32)
+        w30[:pcm.size] = pcm.astype(np.float32) / 32768.0
+        waves.append(w30)
+    mel = LogMelFrontend()(torch.from_numpy(np.stack(waves)).cuda())
+    enc = wt.WhisperEncoderEngine((eng / "WhisperEncoder.engine").read_bytes())
+    dec = wt.WhisperDecoderEngine((eng / "WhisperDecoder.engine").read_bytes(), cfg)
+    want = WhisperTokenDecoder.from_dir(str(ckpt)).batch_decode(dec.generate(enc(mel)).cpu().tolist(), skip_special_tokens=True)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "whisper", "run.py"), "--engine_dir", str(eng), "--whisper", str(ckpt),
+                          "--audio"] + paths, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for k, text in enumerate(want):
+        assert f"clip{k}.wav: {text!r}" in out.stdout, out.stdout[-1500:]
