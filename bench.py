@@ -194,6 +194,24 @@ def main():
                                    "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
                                    "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,
                                    "enc_attn_total_ms": round(ms_eattn, 3)}
+        # whole decode phase against the HBM roofline: algorithmic bytes of step t for a batch of B =
+        #   4*P_step + B*[ 4*L*2*H*S*64 (cross KV) + 4*L*2*H*(t+1)*64 (self KV read) + 4*L*2*H*64 (append) + 4*V (logits) ]
+        n_steps = args.max_length - 1
+        hidden = enc(mel)
+        dec.begin(hidden)
+        torch.cuda.synchronize()
+        t_dec0 = time.perf_counter()
+        dec.steps(n_steps)
+        torch.cuda.synchronize()
+        t_dec = time.perf_counter() - t_dec0
+        p_step = L * (6 * d * d + 2 * d * cfg["decoder_ffn_dim"]) + V * d
+        per_utt_fixed = 4 * L * 2 * H * S * 64 + 4 * L * 2 * H * 64 + 4 * V
+        bytes_total = n_steps * (4 * p_step + B * per_utt_fixed) + B * 4 * L * 2 * H * 64 * (n_steps * (n_steps + 1) // 2)
+        out["roofline_decode"] = {"bound": "hbm", "achieved": round(bytes_total / t_dec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(bytes_total / t_dec / 1e9 / HBM_PEAK_GBS, 4), "steps": n_steps,
+                                  "ms_per_step": round(t_dec / n_steps * 1e3, 4), "bytes_per_step_avg": int(bytes_total / n_steps),
+                                  "launches_per_step": 7 * L + 3,
+                                  "note": "all decoder steps of one batch, wall clock over the replayed step graphs"}
         vocab_bytes = V * d * 4
         out["roofline_vocab_proj"] = {"bound": "hbm", "achieved": round(vocab_bytes / (ms_vocab / max(1, n_vocab) * 1e-3) / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(ms_vocab / max(1, n_vocab) * 1e3, 2)}
