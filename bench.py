@@ -216,7 +216,7 @@ def main():
         out["roofline_vocab_proj"] = {"bound": "hbm", "achieved": round(vocab_bytes / (ms_vocab / max(1, n_vocab) * 1e-3) / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(ms_vocab / max(1, n_vocab) * 1e3, 2)}
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the other ranks would idle behind it)
         # CPU baseline: the oracle (torch-CPU fp32 port of the reference's bundled HF path) on this box's host cores,
         # bounded sample: 1 utterance, full encoder + a few decoder steps; per-step time extrapolated to max_length-1.
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
