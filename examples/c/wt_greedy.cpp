@@ -1,0 +1,82 @@
+// Plain C/C++ host for the C-ABI (no Python, no torch): engines built by build_encoder.py / build_decoder.py, a float32
+// log-mel file, greedy decode, token ids on stdout.  This is what a non-Python embedder of the reference's hot path links:
+// only include/whisper_trtllm_amd.h and the HIP runtime for device buffers.
+//
+//   hipcc -O2 -Iinclude examples/c/wt_greedy.cpp -Lwhisper-trtllm_amd/lib -lwhisper_trtllm_amd -Wl,-rpath,$PWD/whisper-trtllm_amd/lib -o wt_greedy
+//   ./wt_greedy WhisperEncoder.engine WhisperDecoder.engine mel.f32 <batch> rules.txt
+//
+// rules.txt (whitespace separated integers): decoder_start eos pad max_length begin_index
+//   n_suppress s_1 .. s_n   n_begin_suppress b_1 .. b_n   n_forced (index token)_1 .. (index token)_n
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "whisper_trtllm_amd.h"
+
+static std::vector<char> read_file(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)n);
+    if (n > 0 && fread(buf.data(), 1, (size_t)n, f) != (size_t)n) { fprintf(stderr, "short read on %s\n", path); exit(2); }
+    fclose(f);
+    return buf;
+}
+
+#define WT(call) do { int rc_ = (call); if (rc_ != WT_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, wt_last_error()); return 1; } } while (0)
+#define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc != 6) { fprintf(stderr, "usage: %s <encoder.engine> <decoder.engine> <mel.f32> <batch> <rules.txt>\n", argv[0]); return 2; }
+    const int batch = atoi(argv[4]);
+    std::vector<char> enc_blob = read_file(argv[1]), dec_blob = read_file(argv[2]), mel = read_file(argv[3]);
+
+    std::vector<int> rules;
+    { FILE* f = fopen(argv[5], "r"); if (!f) { fprintf(stderr, "cannot open %s\n", argv[5]); return 2; } int v; while (fscanf(f, "%d", &v) == 1) rules.push_back(v); fclose(f); }
+    size_t at = 0;
+    auto next = [&]() { if (at >= rules.size()) { fprintf(stderr, "rules file too short\n"); exit(2); } return rules[at++]; };
+    wt_greedy_params gp = {};
+    gp.decoder_start_token_id = next(); gp.eos_token_id = next(); gp.pad_token_id = next(); gp.max_length = next(); gp.begin_index = next();
+    std::vector<int32_t> suppress((size_t)next()); for (auto& x : suppress) x = next();
+    std::vector<int32_t> begin_suppress((size_t)next()); for (auto& x : begin_suppress) x = next();
+    std::vector<int32_t> forced(2 * (size_t)next()); for (auto& x : forced) x = next();
+    gp.suppress_tokens = suppress.data(); gp.n_suppress_tokens = (int)suppress.size();
+    gp.begin_suppress_tokens = begin_suppress.data(); gp.n_begin_suppress_tokens = (int)begin_suppress.size();
+    gp.forced_decoder_ids = forced.data(); gp.n_forced = (int)forced.size() / 2;
+    gp.force_eos_step = -1; gp.logits_trace = nullptr;
+
+    wt_engine *enc = nullptr, *dec = nullptr;
+    WT(wt_engine_open(enc_blob.data(), enc_blob.size(), 0, &enc));
+    WT(wt_engine_open(dec_blob.data(), dec_blob.size(), 0, &dec));
+    wt_engine_info ei;
+    WT(wt_engine_get_info(enc, &ei));
+    const size_t mel_floats = (size_t)batch * ei.n_mels * 2 * ei.max_source_positions;
+    if (mel.size() != mel_floats * sizeof(float)) { fprintf(stderr, "mel file holds %zu bytes, expected %zu\n", mel.size(), mel_floats * sizeof(float)); return 2; }
+
+    hipStream_t stream;
+    HIP(hipStreamCreate(&stream));
+    float *d_mel = nullptr, *d_hidden = nullptr;
+    int32_t* d_ids = nullptr;
+    HIP(hipMalloc((void**)&d_mel, mel.size()));
+    HIP(hipMalloc((void**)&d_hidden, (size_t)batch * ei.max_source_positions * ei.d_model * sizeof(float)));
+    HIP(hipMalloc((void**)&d_ids, (size_t)batch * gp.max_length * sizeof(int32_t)));
+    HIP(hipMemcpyAsync(d_mel, mel.data(), mel.size(), hipMemcpyHostToDevice, stream));
+    WT(wt_encoder_forward(enc, d_mel, batch, d_hidden, stream));
+    int out_len = 0;
+    WT(wt_decoder_greedy(dec, d_hidden, batch, &gp, d_ids, &out_len, stream));
+    std::vector<int32_t> ids((size_t)batch * gp.max_length);
+    HIP(hipMemcpy(ids.data(), d_ids, ids.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b) {
+        for (int t = 0; t < out_len; ++t) printf(t ? " %d" : "%d", ids[(size_t)b * gp.max_length + t]);
+        printf("\n");
+    }
+    (void)hipFree(d_mel); (void)hipFree(d_hidden); (void)hipFree(d_ids);
+    wt_engine_close(enc);
+    wt_engine_close(dec);
+    (void)hipStreamDestroy(stream);
+    return 0;
+}

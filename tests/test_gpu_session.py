@@ -270,3 +270,33 @@ def test_run_py_transcribes_audio_files(wt, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     for k, text in enumerate(want):
         assert f"clip{k}.wav: {text!r}" in out.stdout, out.stdout[-1500:]
+
+
+def test_plain_c_host_of_the_c_abi(wt, tmp_path):
+    """examples/c/wt_greedy: a C/C++ program that uses ONLY include/whisper_trtllm_amd.h + the HIP runtime (no Python, no torch in
+    the process) reads engine files, a raw float32 log-mel file and the token rules, and prints the same ids as the golden file."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "c", "wt_greedy")
+    if not os.path.exists(exe):   # normally built by __graft_entry__.build(); hipcc is in the image
+        spec = importlib.util.spec_from_file_location("_wt_build", os.path.join(ROOT, "whisper-trtllm_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_c_example()
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    (tmp_path / "enc.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
+    (tmp_path / "dec.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
+    np.ascontiguousarray(mel, dtype=np.float32).tofile(tmp_path / "mel.f32")
+    forced = cfg.get("forced_decoder_ids") or []
+    begin_index = (1 if cfg.get("forced_bos_token_id") is None else 2) + (forced[-1][0] if forced else 0)
+    rules = [cfg["decoder_start_token_id"], cfg["eos_token_id"], cfg["pad_token_id"], cfg["max_length"], begin_index]
+    for lst in (cfg.get("suppress_tokens") or [], cfg.get("begin_suppress_tokens") or []):
+        rules += [len(lst)] + list(lst)
+    rules += [len(forced)] + [x for pair in forced for x in pair]
+    (tmp_path / "rules.txt").write_text(" ".join(str(int(x)) for x in rules))
+    out = subprocess.run([exe, str(tmp_path / "enc.engine"), str(tmp_path / "dec.engine"), str(tmp_path / "mel.f32"), str(mel.shape[0]),
+                          str(tmp_path / "rules.txt")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = np.array([[int(t) for t in line.split()] for line in out.stdout.strip().splitlines()])
+    want = z["ids"]
+    np.testing.assert_array_equal(got, want[:, :got.shape[1]])
+    assert got.shape[0] == want.shape[0] and (want[:, got.shape[1]:] == cfg["pad_token_id"]).all()

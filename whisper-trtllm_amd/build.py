@@ -54,5 +54,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_c_example(verbose: bool = False) -> str:
+    """examples/c/wt_greedy: a plain C/C++ host of the C-ABI (no Python, no torch), linked against the library above."""
+    root = os.path.dirname(HERE)
+    src, exe = os.path.join(root, "examples", "c", "wt_greedy.cpp"), os.path.join(root, "examples", "c", "wt_greedy")
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(root, "include", "whisper_trtllm_amd.h")), os.path.getmtime(LIB_PATH))
+    if os.path.exists(exe) and os.path.getmtime(exe) >= newest:
+        return exe
+    cmd = [_hipcc(), "-O2", "-I" + os.path.join(root, "include"), src, "-L" + LIB_DIR, "-lwhisper_trtllm_amd",
+           "-Wl,-rpath,$ORIGIN/../../whisper-trtllm_amd/lib", "-o", exe]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_c_example(verbose=True))
