@@ -134,9 +134,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
 
     // ---- activation slice -> registers -------------------------------------------------------------------
     // vmcnt retires in issue order, so whatever is requested first is waited for first: with LDS staging the activation
-    // rows (L2 / Infinity-Cache hits, ~1 us) go out BEFORE the first W rows (HBM, 2+ us under the burst) and the
-    // LayerNorm + staging + barrier run while the weights are still in flight; measured with in-kernel timestamps the
-    // other order left the whole prologue behind the arrival of the weights.
+    // rows go out before the first W rows.  (Measured neutral either way: the rows were written by the previous kernel on
+    // other XCDs, so they arrive from the memory side together with the first weights, ~1.6-2.2 us after the start;
+    // the LayerNorm + staging + barrier that follow are ~0.4-1 us of the launch -- DESIGN.md, timestamp study.)
     const bool staged = p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2) && !p.parts);
     if (!staged && row_begin < row_end) wload(0, row_begin);
     if (staged) {
