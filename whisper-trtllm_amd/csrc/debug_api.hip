@@ -37,7 +37,7 @@ extern "C" int wt_dbg_decode_attention(const float* q, const float* kcache, cons
     DecAttnParams a;
     memset(&a, 0, sizeof a);
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.cnt = cnt; a.out = out; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
-    a.fixed_len = len;
+    a.fixed_len = len; a.nt = 1;
     return rc_of(launch_dec_attn(a, (hipStream_t)stream));
 }
 extern "C" int wt_dbg_decode_attention_folded(const float* u, const float* kcache, const float* vcache, float* part, int* cnt,
@@ -47,7 +47,7 @@ extern "C" int wt_dbg_decode_attention_folded(const float* u, const float* kcach
     DecAttnParams a;
     memset(&a, 0, sizeof a);
     a.q = u; a.kcache = kcache; a.vcache = vcache; a.part = part; a.cnt = cnt; a.out = out; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
-    a.fixed_len = len; a.ln_h = ln_h; a.ln_r = ln_r; a.ln_t = ln_t;
+    a.fixed_len = len; a.nt = 1; a.ln_h = ln_h; a.ln_r = ln_r; a.ln_t = ln_t;
     return rc_of(launch_dec_attn(a, (hipStream_t)stream));
 }
 extern "C" int wt_dbg_attention_then_projection(const float* q, const float* kcache, const float* vcache, float* part, const float* W,
@@ -57,7 +57,7 @@ extern "C" int wt_dbg_attention_then_projection(const float* q, const float* kca
     DecAttnParams a;
     memset(&a, 0, sizeof a);
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split;
-    a.fixed_len = len; a.defer_merge = 1;
+    a.fixed_len = len; a.nt = 1; a.defer_merge = 1;
     int rc = rc_of(launch_dec_attn(a, (hipStream_t)stream));
     if (rc) return rc;
     SkinnyParams k;

@@ -96,6 +96,7 @@ struct wt_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_valid = false, use_graph = true;
+    int nt_loads = 1;  // stream weights and K/V with non-temporal loads (set per decode in wt_decoder_begin)
     // Session-compat shapes (set by infer_shapes)
     bool shapes_ok = false;
     int c_B = 1, c_s = 0, c_ms = 0, c_mc = 0;
@@ -528,26 +529,26 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         memset(&k, 0, sizeof k);
         k.X = h; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
         k.Y = e->dq; k.kcache = sk; k.vcache = sv; k.st = e->st; k.B = B; k.N = 3 * d; k.K = d; k.ymode = YMODE_QKV_APPEND;
-        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = 1;
+        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = e->nt_loads;
         LAUNCH(launch_skinny(k, s));
         memset(&a, 0, sizeof a);
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
-        a.n_split = io.nsplit_self; a.fixed_len = 0;
+        a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads;
         LAUNCH(launch_dec_attn(a, s));
         // --- ONE launch: out-projection + residual (h1 = h + Wo.a + bo) and the folded cross-attention query
         //     u = s.Wq.diag(gamma2).(h + Wo.a + bo) = fold_w.[a ; h] + fold_c; LayerNorm statistics of h1 are applied
         //     by the cross-attention kernel (model.py:261-272 semantics, one dependent launch fewer per layer)
         memset(&k, 0, sizeof k);
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = h;
-        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
+        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         memset(&k2, 0, sizeof k2);
         k2.X = e->datt; k2.X2 = h; k2.xmode = XMODE_PLAIN; k2.x_direct = 1; k2.W = l.fold_w; k2.bias = l.fold_c;
-        k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = 1;
+        k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = e->nt_loads;
         LAUNCH(launch_skinny_pair(k, k2, s));
         // --- cross attention over the encoder memory: K/V already resident
         memset(&a, 0, sizeof a);
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
-        a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t;
+        a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t;
         a.defer_merge = defer && io.nsplit_cross == 2;  // the out-projection below merges the two split partials while staging them
                                                         // (more splits, i.e. batch < 8: the attention kernel merges its own, by ticket)
         {
@@ -558,24 +559,24 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
         }
         memset(&k, 0, sizeof k);
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = h1;
-        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
+        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         if (defer && io.nsplit_cross == 2) { k.parts = e->part; k.parts_nsplit = io.nsplit_cross; k.parts_H = H; }
         LAUNCH(launch_skinny(k, s));
         // --- FFN (model.py:363-367)
         memset(&k, 0, sizeof k);
         k.X = h1; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
-        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = 1;
+        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         LAUNCH(launch_skinny(k, s));
         memset(&k, 0, sizeof k);
         k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = h1; k.Y = h1; k.st = e->st;
-        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = 1;
+        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         LAUNCH(launch_skinny(k, s));
         std::swap(h, h1);
     }
     // final LN + vocabulary projection (model.py:455-457; logits are the engine's 'hidden_states' output)
     memset(&k, 0, sizeof k);
     k.X = h; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
-    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
+    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
     {
         hipEvent_t ta, tb;
         timer_begin(e, e->t_skinny, s, &ta, &tb);
@@ -642,6 +643,16 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     e->pad = p->pad_token_id; e->force_eos_step = p->force_eos_step; e->trace = p->logits_trace;
     // measured (tools/microbench.py, medium.en B=8): self attention is fastest unsplit at every length <= 448;
     // cross attention (1500 keys) with ~one block per CU
+    {   // Everything a step touches is read exactly once per step: stream it non-temporally -- unless one whole step (weights + this
+        // batch's K/V) fits the 256 MB Infinity Cache, where default-policy loads let step t+1 hit what step t brought in.
+        // Measured ms per step, non-temporal vs default: tiny.en B=1 (136 MB) 0.171 vs 0.160; tiny.en B=8 (300 MB) 0.224 vs 0.221;
+        // base.en B=8 0.324 vs 0.340; small.en B=8 0.688 vs 0.711; medium.en B=8 1.61 vs 1.66.
+        const double p_step = (double)e->L * (6.0 * e->d * e->d + 2.0 * e->d * e->F) + (double)e->V * e->d;
+        const double step_bytes = 4.0 * p_step + (double)B * 2.0 * e->L * e->H * ((double)e->S + p->max_length) * HEAD_DIM * 4.0;
+        const int nt = step_bytes > 160e6;
+        if (nt != e->nt_loads) e->graph_valid = false;
+        e->nt_loads = nt;
+    }
     e->nsplit_self = 1;
     e->nsplit_cross = getenv("WT_NSPLIT_CROSS") ? atoi(getenv("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
@@ -898,7 +909,7 @@ extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* a
         a.q = e->dq; a.kcache = e->cross_k + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
         a.vcache = e->cross_v + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
         a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = e->B; a.H = e->H; a.s_cap = e->S;
-        a.n_split = e->nsplit_cross; a.fixed_len = e->S;
+        a.n_split = e->nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads;
         a.ln_h = e->dh2; a.ln_r = e->dec_layers[i].fold_r; a.ln_t = e->dec_layers[i].fold_t;  // as in the decode step
         a.defer_merge = e->nsplit_cross == 2 && getenv("WT_NO_DEFER_MERGE") == nullptr;
         le = launch_dec_attn(a, e->own_stream);

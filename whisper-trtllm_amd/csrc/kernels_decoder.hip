@@ -627,17 +627,17 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     if (lane == 0) p.cnt[b * p.H + h] = 0;  // re-arm the ticket for the next launch (kernel boundary orders it)
 }
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
-    static int variant = -1;
+    static int variant = -1;  // A/B override: WT_ATTN_VARIANT=0 forces default-policy loads, 1 forces non-temporal loads
     if (variant < 0) {
         const char* e = getenv("WT_ATTN_VARIANT");
-        variant = e ? atoi(e) : 1;
+        variant = e ? atoi(e) : 2;
     }
     const dim3 grid(p.n_split, p.H, p.B);
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((dec_attn_kernel<4, false>), grid, dim3(256), 0, s, p); break;  // A/B: default-policy loads
-        default: hipLaunchKernelGGL((dec_attn_kernel<4, true>), grid, dim3(256), 0, s, p); break;  // measured best: 18.6 vs 20.4 us
-    
-    }
+    const bool nt = variant == 2 ? p.nt != 0 : variant != 0;
+    // non-temporal K/V loads: 18.6 vs 20.4 us per medium.en cross-attention launch; default policy only when a whole decode
+    // step fits the Infinity Cache (engine.hip: wt_decoder_begin)
+    if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((dec_attn_kernel<4, false>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

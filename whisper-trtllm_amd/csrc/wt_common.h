@@ -97,6 +97,7 @@ struct DecAttnParams {
     int B, H, s_cap;
     int n_split;
     int fixed_len;         // >0: number of keys (cross attention); 0: use st->self_len + 1
+    int nt;                // stream K/V with non-temporal loads (0: default cache policy)
     int defer_merge;       // n_split > 1: leave the split partials in `part` (plain stores, no ticket); the consumer GEMV merges them
     // folded cross-attention query: q holds u = s.Wq.diag(gamma).h1 (+ const) and the kernel finishes the
     // LayerNorm per row: q = (u - mean(h1) . ln_r) * rstd(h1) + ln_t.  ln_h == nullptr: q is used as it is.
