@@ -493,9 +493,9 @@ static int pick_splits(int B, int H, int len) {
     // Key splits of the cross-attention launch.  Two splits are merged for free by the consuming GEMV (deferred merge), more
     // are merged by the attention kernel's last-arriving block, which costs ~2 us: measured on medium.en, ms per step at
     // B = 1: 16 splits 1.25, 8: 1.12, 4: 1.09, 2: 1.14;  B = 2: 8: 1.16, 4: 1.12, 2: 1.15;  B = 4: 4: 1.27, 2: 1.26;
-    // B = 8: 2: 1.47, 3: 1.76, 4: 1.80.  So: 4 while (utterance, head) pairs are scarce, else 2, none from 256 pairs up.
+    // B = 8: 2: 1.47, 3: 1.76, 4: 1.80.  So: 4 while (utterance, head) pairs are scarce (<= 64), else 2, none from 256 pairs up.
     int n = (256 + B * H - 1) / (B * H);
-    n = n >= 8 ? 4 : n >= 2 ? 2 : 1;
+    n = n >= 4 ? 4 : n >= 2 ? 2 : 1;   // (tiny.en B = 8, 48 pairs: 4 splits 0.218, 2 splits 0.225; small.en B = 8, 96 pairs: 2 splits 0.693, 4: 0.706)
     while (n > 1 && len / n < 48) n >>= 1;
     return n;
 }
