@@ -44,4 +44,5 @@ def sub(a):
     return np.ascontiguousarray(a[..., ::max(1, a.shape[-2] // 24), ::max(1, a.shape[-1] // 32)])
 
 
-GOLDEN_CASES = ["toy-short_b3", "toy-short-eos1_b3", "toy-short-eosall_b3", "toy-wide_b2", "toy_b1", "tiny_b2"]
+# tiny-long_b2: a full 447-step generation of the reference (self-cache length / position rows up to 447)
+GOLDEN_CASES = ["toy-short_b3", "toy-short-eos1_b3", "toy-short-eosall_b3", "toy-wide_b2", "toy_b1", "tiny_b2", "tiny-long_b2"]

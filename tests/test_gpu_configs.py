@@ -2,7 +2,15 @@
 
 config 2  whisper-tiny.en  fp32, batch 1               -> full parity against the CPU oracle
 config 3  whisper-small.en fp32, batch 8, KV cache on  -> oracle parity on 2 rows + batch-independence on all 8
+config 4  whisper-medium.en fp16 encoder + fp32 decoder, batch 16 -> encoder within 1e-2 of the fp32 oracle's range on
+          1 row (parity unpinned: the reference holds no fp16 fixture), decoder logits/ids against the oracle run on the
+          ENGINE's fp16 encoder memory (the decoder is fp32: bit-exact ids, logits 1e-3), row independence on all 16
 config 5  whisper-medium.en fp32, batch 8 per GPU      -> oracle parity on 1 row + batch-independence on all 8
+long      whisper-small.en fp32, batch 8, 128 steps    -> all ids + logits against the oracle (the benchmark's regime:
+          hundreds of graph replays, self-cache lengths far beyond the 32-token goldens)
+Seeds / mel indices were picked with tests/golden/find_healthy_seeds.py: the oracle's minimum top-2 margin is >= 4e-2 on
+every decision asserted here, three orders above the GPU's logit error, so ids are asserted UNCONDITIONALLY (a margin
+below 1e-3 fails the test instead of skipping the comparison).
 At these sizes the oracle only runs a few rows / steps (seconds of CPU); the rest is covered by properties the domain
 offers: utterances are independent, so row b of a batch-8 decode must equal the same utterance decoded alone."""
 import numpy as np
@@ -42,6 +50,12 @@ def _oracle(cfg, weights, mel, steps):
     return h, ids, logits
 
 
+def _assert_healthy_margin(logits_ref, floor=1e-3):
+    top2 = torch.topk(logits_ref[:, 1:], 2, dim=-1).values      # step 0 emits the forced token whatever the logits
+    margin = (top2[..., 0] - top2[..., 1]).min().item()
+    assert margin > floor, f"oracle top-2 margin {margin:.2e}: pick another seed (tests/golden/find_healthy_seeds.py)"
+
+
 @pytest.mark.parametrize("name,batch,oracle_rows,steps", [
     ("whisper-tiny.en", 1, 1, 12),      # config 2
     ("whisper-small.en", 8, 2, 6),      # config 3
@@ -59,12 +73,62 @@ def test_baseline_config(wt, name, batch, oracle_rows, steps):
     scale = h_ref.abs().max().item()
     assert (hidden[:oracle_rows].cpu() - h_ref).abs().max().item() < 3e-4 * max(1.0, scale)
     assert (trace[:oracle_rows].cpu() - logits_ref).abs().max().item() < 1e-3
-    top2 = torch.topk(logits_ref, 2, dim=-1).values
-    if (top2[..., 0] - top2[..., 1]).min().item() > 1e-3:
-        np.testing.assert_array_equal(ids[:oracle_rows].cpu().numpy(), ids_ref.numpy())
+    _assert_healthy_margin(logits_ref)
+    np.testing.assert_array_equal(ids[:oracle_rows].cpu().numpy(), ids_ref.numpy())
     # batch independence: every row decoded alone gives the same ids and (to rounding) the same logits
     for b in range(0, batch, max(1, batch // 4)):
         t1 = torch.zeros(1, steps, cfg["vocab_size"], dtype=torch.float32, device="cuda")
         one = dec.generate(enc(torch.from_numpy(mel[b:b + 1]).cuda()), max_length=steps + 1, logits_trace=t1)
         assert (t1[0] - trace[b]).abs().max().item() < 2e-4
+        np.testing.assert_array_equal(one.cpu().numpy()[0], ids[b].cpu().numpy())
+
+
+def test_long_decode_small_en_batch8_matches_oracle(wt):
+    """128 decoder steps of whisper-small.en at batch 8 (KV cache on), every row against the oracle: all ids exact, all
+    logits within 1e-3.  Oracle minimum margin for this (seed, mel) pair: 7.9e-2 over 8 x 160 decisions."""
+    name, batch, steps = "whisper-small.en", 8, 128
+    cfg = wt.synthetic.get_config(name)
+    weights = wt.synthetic.make_weights(cfg, 77)
+    mel = wt.synthetic.make_mel(cfg, index=300, batch=batch)
+    enc, dec, hidden, trace, ids = _run(wt, cfg, weights, mel, steps)
+    h_ref, ids_ref, logits_ref = _oracle(cfg, weights, mel, steps)
+    _assert_healthy_margin(logits_ref)
+    assert (hidden.cpu() - h_ref).abs().max().item() < 3e-4 * max(1.0, h_ref.abs().max().item())
+    err = (trace.cpu() - logits_ref).abs().amax(dim=(0, 2))           # per step
+    assert err.max().item() < 1e-3, f"logits differ by {err.max().item():.2e} at step {int(err.argmax())}"
+    np.testing.assert_array_equal(ids.cpu().numpy(), ids_ref.numpy())
+
+
+def test_config4_fp16_encoder_fp32_decoder_batch16(wt):
+    """BASELINE config 4 at its real size: whisper-medium.en, fp16 encoder engine + fp32 decoder engine, batch 16.
+    (a) fp16 encoder memory within 1e-2 of the fp32 oracle's dynamic range on row 0 -- a tolerance, parity unpinned: the
+        reference publishes no fp16 result (README.md:82-88);
+    (b) the fp32 decoder on that memory against the oracle's decoder on the SAME memory: logits 1e-3, ids exact;
+    (c) utterances are independent: rows decoded alone give the same ids as in the batch of 16."""
+    import cpu_ref
+    cfg = wt.synthetic.get_config("whisper-medium.en")
+    weights = wt.synthetic.make_weights(cfg, 77)
+    B, steps, V = 16, 5, cfg["vocab_size"]
+    mel = wt.synthetic.make_mel(cfg, index=300, batch=B)
+    enc16 = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights, precision="float16"))
+    dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
+    hidden = enc16(torch.from_numpy(mel).cuda())
+    trace = torch.zeros(B, steps, V, dtype=torch.float32, device="cuda")
+    ids = dec.generate(hidden, max_length=steps + 1, logits_trace=trace)
+    assert torch.isfinite(hidden).all() and torch.isfinite(trace).all() and tuple(ids.shape) == (B, steps + 1)
+    W = cpu_ref.to_torch(weights)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        h_ref = cpu_ref.encoder_forward(W, cfg, torch.from_numpy(mel[:1]))
+        scale = h_ref.abs().max().item()
+        err = (hidden[:1].cpu() - h_ref).abs().max().item()
+        assert err < 1e-2 * scale, (err, scale)
+        ids_ref, logits_ref = cpu_ref.greedy_search(W, cfg, hidden[:2].cpu(), max_length=steps + 1, return_logits=True)
+    _assert_healthy_margin(logits_ref)
+    assert (trace[:2].cpu() - logits_ref).abs().max().item() < 1e-3
+    np.testing.assert_array_equal(ids[:2].cpu().numpy(), ids_ref.numpy())
+    for b in (0, 5, 10, 15):
+        t1 = torch.zeros(1, steps, V, dtype=torch.float32, device="cuda")
+        one = dec.generate(enc16(torch.from_numpy(mel[b:b + 1]).cuda()), max_length=steps + 1, logits_trace=t1)
+        assert (t1[0] - trace[b]).abs().max().item() < 2e-3   # fp16 GEMM tiles see other rows' positions: not bit-equal
         np.testing.assert_array_equal(one.cpu().numpy()[0], ids[b].cpu().numpy())
