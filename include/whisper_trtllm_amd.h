@@ -20,6 +20,7 @@
  *     workspace and the resident KV cache.  No torch types appear in any signature.
  *   - calls are stream-ordered on the `hipStream_t` passed as `void* stream`; only wt_decoder_poll and
  *     wt_decoder_greedy synchronise (documented below).  First use with a new batch size allocates workspace.
+ *   - every call runs on its handle's device and restores the caller's current device before returning.
  *   - one handle per device; a handle is NOT thread-safe (matches one IExecutionContext per Session,
  *     session.py:48); distinct handles may be driven concurrently.
  */
@@ -119,7 +120,9 @@ typedef struct {
 /* (6) start a greedy decode of `batch` utterances (1 <= batch <= 16 per call, WT_E_UNSUPPORTED above; shard larger
  * batches over calls or GPUs): project the encoder memory f32 [batch,S,d] into the
  * resident cross-KV cache, reset the self-KV cache and the id buffer to [[decoder_start_token_id]]*batch.
- * Replaces greedy_search() step 0 (run.py:171-197 with past_key_values=None).  Asynchronous. */
+ * Replaces greedy_search() step 0 (run.py:171-197 with past_key_values=None).  Asynchronous when the token rules
+ * (suppress / begin-suppress / forced lists) equal those of the previous decode on this handle; a changed rule set is
+ * uploaded and the stream synchronised once. */
 int wt_decoder_begin(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p, void* stream);
 /* (7) enqueue `n_steps` decoder steps (token embed -> L layers -> vocab projection -> logits processors ->
  * argmax -> pad/EOS bookkeeping -> append), all on device.  Steps after every row finished are no-ops.

@@ -40,6 +40,41 @@ def test_open_rejects_garbage_and_reports():
     assert not h.value
 
 
+def test_open_rejects_wrapping_offsets_through_the_c_abi():
+    """64-bit table/tensor offsets chosen so that `offset + size` wraps past 2^64: the C-ABI must refuse them before any
+    device work (the old checks were sums of file-controlled terms).  The exhaustive version of this runs under
+    ASan/UBSan in tests/test_host_sanitizer.py; here the shipped library itself is checked."""
+    import struct
+    lib = _lib.load()
+    cfg = synthetic.get_config("toy-short")
+    good = bytes(convert.build_encoder_engine(cfg, synthetic.make_weights(cfg, 1)))
+    n_tensors, = struct.unpack_from("<I", good, 20)
+    table_off, data_off, total = struct.unpack_from("<QQQ", good, 120)
+    assert total == len(good)
+
+    def patched(off, fmt, val):
+        b = bytearray(good)
+        struct.pack_into(fmt, b, off, val)
+        return bytes(b)
+    cases = {
+        "table_off wraps": patched(120, "<Q", 2 ** 64 - n_tensors * 152),
+        "table_off near 2^64": patched(120, "<Q", 2 ** 64 - 100),
+        "n_tensors huge": patched(20, "<I", 2 ** 32 - 1),
+        "data_off inside table": patched(128, "<Q", table_off + 16),
+        "tensor offset wraps": patched(table_off + 136, "<Q", 2 ** 64 - 4096),
+        "tensor nbytes huge": patched(table_off + 144, "<Q", 2 ** 64 - 1),
+        "dimension product wraps": patched(table_off + 104, "<q", 2 ** 62),
+    }
+    h = ctypes.c_void_p()
+    for what, blob in cases.items():
+        rc = lib.wt_engine_open(blob, len(blob), 0, ctypes.byref(h))
+        assert rc == -22 and not h.value, (what, rc, _lib.last_error())
+    half = bytes(convert.build_encoder_engine(cfg, synthetic.make_weights(cfg, 1), precision="float16"))
+    bad = bytearray(half)
+    struct.pack_into("<i", bad, 24 + 4 * 3, cfg["d_model"] // 2)          # cfg[CFG_FFN] < d_model in an fp16 engine
+    assert lib.wt_engine_open(bytes(bad), len(bad), 0, ctypes.byref(h)) == -22 and "ffn_dim >= d_model" in _lib.last_error()
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

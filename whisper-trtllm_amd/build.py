@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwhisper_trtllm_amd.so")
-SOURCES = ["engine.hip", "frontend.hip", "debug_api.hip", "kernels_encoder.hip", "kernels_encoder_f16.hip", "kernels_decoder.hip"]
-HEADERS = ["wt_common.h", os.path.join("..", "..", "include", "whisper_trtllm_amd.h"),
+SOURCES = ["engine.hip", "host_logic.cpp", "frontend.hip", "debug_api.hip", "kernels_encoder.hip", "kernels_encoder_f16.hip", "kernels_decoder.hip"]
+HEADERS = ["wt_common.h", "host_logic.h", os.path.join("..", "..", "include", "whisper_trtllm_amd.h"),
            os.path.join("..", "..", "include", "whisper_trtllm_amd_debug.h")]
 
 
@@ -40,7 +40,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

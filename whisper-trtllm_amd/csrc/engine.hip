@@ -87,6 +87,9 @@ struct wt_engine {
     DecState* st = nullptr;
     int *ids = nullptr, *unfinished = nullptr, *forced = nullptr;
     uint8_t* mask = nullptr;
+    std::vector<uint8_t> h_mask;   // host images of the device rule tables (wt_decoder_begin uploads only on change)
+    std::vector<int> h_forced;
+    bool tables_valid = false;
     DecState* h_state = nullptr;  // pinned
     // greedy session
     bool begun = false;
@@ -145,7 +148,7 @@ extern "C" const char* wt_last_error(void) { return g_err; }
 
 extern "C" void wt_engine_close(wt_engine* e) {
     if (!e) return;
-    hipSetDevice(e->device);
+    DeviceGuard guard(e->device);
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
     for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) {
@@ -166,40 +169,25 @@ extern "C" void wt_engine_close(wt_engine* e) {
 extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_engine** out) {
     if (!blob || !out) return fail(WT_E_INVALID, "wt_engine_open: null argument");
     *out = nullptr;
-    if (nbytes < sizeof(BlobHeader)) return fail(WT_E_INVALID, "engine blob too small (%zu bytes)", nbytes);
-    BlobHeader hd;
-    memcpy(&hd, blob, sizeof hd);
-    if (memcmp(hd.magic, "WTENGINE", 8) != 0) return fail(WT_E_INVALID, "engine blob has bad magic");
-    if (hd.version != 2) return fail(WT_E_UNSUPPORTED, "engine blob version %u not supported (this library reads version 2; rebuild the engine)", hd.version);
-    if (hd.total_bytes != nbytes || hd.table_off + (uint64_t)hd.n_tensors * sizeof(BlobTensor) > nbytes ||
-        hd.data_off > nbytes)
-        return fail(WT_E_INVALID, "engine blob is truncated or corrupt (header says %llu bytes, got %zu)",
-                    (unsigned long long)hd.total_bytes, nbytes);
-    if (hd.kind != WT_KIND_ENCODER && hd.kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "unknown engine kind %u", hd.kind);
-    if (hd.precision != WT_F32 && !(hd.precision == WT_F16 && hd.kind == WT_KIND_ENCODER))
-        return fail(WT_E_UNSUPPORTED, "engine precision %u: float32, or float16 for the encoder engine only", hd.precision);
+    ParsedBlob pb;
+    {
+        char msg[400] = "";
+        const int prc = parse_blob(blob, nbytes, &pb, msg, sizeof msg);  // host_logic.cpp: overflow-safe bounds, config limits
+        if (prc) return fail(prc, "%s", msg);
+    }
+    const BlobHeader& hd = pb.hd;
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(WT_E_INVALID, "device %d out of range (%d visible)", device, ndev);
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail(WT_E_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(guard.err));
 
     wt_engine* e = new wt_engine();
-    e->kind = (int)hd.kind;
-    e->precision = (int)hd.precision;
+    e->kind = pb.dims.kind;
+    e->precision = pb.dims.precision;
     e->device = device;
-    e->d = hd.cfg[CFG_D_MODEL]; e->H = hd.cfg[CFG_HEADS]; e->L = hd.cfg[CFG_LAYERS]; e->F = hd.cfg[CFG_FFN];
-    e->C = hd.cfg[CFG_MELS]; e->S = hd.cfg[CFG_SRC_POS]; e->T = hd.cfg[CFG_TGT_POS]; e->V = hd.cfg[CFG_VOCAB];
-    auto bad = [&](const char* why) {
-        int rc = fail(WT_E_INVALID, "engine config invalid: %s (d=%d H=%d L=%d F=%d C=%d S=%d T=%d V=%d)", why, e->d,
-                      e->H, e->L, e->F, e->C, e->S, e->T, e->V);
-        wt_engine_close(e);
-        return rc;
-    };
-    if (e->d <= 0 || e->H <= 0 || e->d != e->H * HEAD_DIM) return bad("head_dim must be 64");
-    if (e->d > 1024 || (e->d & 3)) return bad("d_model must be a multiple of 4 and <= 1024");
-    if (e->L <= 0 || e->F <= 0 || (e->F & 3) || e->F > 4096) return bad("ffn_dim must be a multiple of 4 and <= 4096");
-    if (e->S <= 0 || e->C <= 0 || e->C > 128 || (e->C & 3)) return bad("num_mel_bins must be a multiple of 4 and <= 128");
-    if (e->kind == WT_KIND_DECODER && (e->T <= 1 || e->V <= 0)) return bad("decoder needs max_target_positions and vocab");
+    e->d = pb.dims.d; e->H = pb.dims.H; e->L = pb.dims.L; e->F = pb.dims.F;
+    e->C = pb.dims.C; e->S = pb.dims.S; e->T = pb.dims.T; e->V = pb.dims.V;
 
     // upload the tensor payload in one allocation
     const size_t payload = nbytes - hd.data_off;
@@ -215,27 +203,12 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         wt_engine_close(e);
         return rc;
     }
-    const BlobTensor* tab = (const BlobTensor*)((const char*)blob + hd.table_off);
-    for (uint32_t i = 0; i < hd.n_tensors; ++i) {
-        BlobTensor bt;
-        memcpy(&bt, tab + i, sizeof bt);
-        bt.name[sizeof(bt.name) - 1] = 0;
-        if (bt.offset < hd.data_off || bt.offset + bt.nbytes > nbytes || (bt.offset & 15) || (bt.dtype != WT_F32 && bt.dtype != WT_F16) || bt.ndim > 4) {
-            int rc = fail(WT_E_INVALID, "tensor '%s' has a bad table entry", bt.name);
-            wt_engine_close(e);
-            return rc;
-        }
+    for (const BlobTensor& bt : pb.tensors) {  // entries were validated by parse_blob
         DevTensor t;
         t.ptr = (float*)(e->weights_base + (bt.offset - hd.data_off));
         t.ndim = (int)bt.ndim;
         t.dtype = (int)bt.dtype;
-        int64_t n = 1;
-        for (uint32_t k = 0; k < bt.ndim; ++k) { t.shape[k] = bt.shape[k]; n *= bt.shape[k]; }
-        if ((uint64_t)n * (bt.dtype == WT_F16 ? 2 : 4) != bt.nbytes) {
-            int rc = fail(WT_E_INVALID, "tensor '%s': shape and byte count disagree", bt.name);
-            wt_engine_close(e);
-            return rc;
-        }
+        for (uint32_t k = 0; k < bt.ndim; ++k) t.shape[k] = bt.shape[k];
         e->w[bt.name] = t;
     }
     // resolve the parameter tree; every lookup failure is reported by name
@@ -408,7 +381,8 @@ static int encoder_forward_f16(wt_engine* e, const float* mel, int B, float* out
 extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* out, void* stream) {
     if (!e || e->kind != WT_KIND_ENCODER) return fail(WT_E_INVALID, "wt_encoder_forward: not an encoder engine");
     if (!mel || !out || B < 1) return fail(WT_E_INVALID, "wt_encoder_forward: bad arguments (batch %d)", B);
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     int rc = enc_reserve(e, B);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -461,6 +435,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     if (B <= e->dec_cap && max_length <= e->dec_maxlen_cap) return WT_OK;
     if (e->dec_ws) { hipFree(e->dec_ws); e->dec_ws = nullptr; e->dec_cap = 0; }
     e->graph_valid = false;
+    e->tables_valid = false;
     const int cap_len = max_length > e->T ? max_length : e->T;
     const size_t d = e->d, kv_self = (size_t)e->L * B * e->H * e->T * HEAD_DIM, kv_cross = (size_t)e->L * B * e->H * e->S * HEAD_DIM;
     size_t off = 0;
@@ -612,11 +587,14 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     auto tok_ok = [&](int t) { return t >= 0 && t < e->V; };
     if (!tok_ok(p->decoder_start_token_id) || !tok_ok(p->eos_token_id) || !tok_ok(p->pad_token_id))
         return fail(WT_E_INVALID, "start/eos/pad token id outside the vocabulary");
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     int rc = dec_reserve(e, B, p->max_length);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    // token rules -> device tables (SuppressTokens / SuppressTokensAtBegin / ForceTokens)
+    // token rules -> device tables (SuppressTokens / SuppressTokensAtBegin / ForceTokens).  The host images live in the engine:
+    // when the rules are the ones of the previous decode (the usual case: one rule set per checkpoint) nothing is uploaded and
+    // the call stays asynchronous; only a CHANGED rule set is uploaded, followed by one stream synchronisation.
     std::vector<uint8_t> mask(e->V, 0);
     for (int i = 0; i < p->n_suppress_tokens; ++i) {
         if (!tok_ok(p->suppress_tokens[i])) return fail(WT_E_INVALID, "suppress token %d outside the vocabulary", p->suppress_tokens[i]);
@@ -632,9 +610,14 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         if (!tok_ok(tok)) return fail(WT_E_INVALID, "forced token %d outside the vocabulary", tok);
         if (idx >= 0 && idx <= e->dec_maxlen_cap) forced[idx] = tok;
     }
-    HIPCHK(hipMemcpyAsync(e->mask, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(e->forced, forced.data(), forced.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));  // the host vectors above die at return
+    if (!e->tables_valid || mask != e->h_mask || forced != e->h_forced) {
+        e->h_mask.swap(mask);
+        e->h_forced.swap(forced);
+        HIPCHK(hipMemcpyAsync(e->mask, e->h_mask.data(), e->h_mask.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(e->forced, e->h_forced.data(), e->h_forced.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));  // pageable sources: make sure the copies have left the host images before they can change
+        e->tables_valid = true;
+    }
     const bool same = e->begun && e->B == B && e->max_length == p->max_length && e->trace == p->logits_trace &&
                       e->begin_index == p->begin_index && e->eos == p->eos_token_id && e->pad == p->pad_token_id &&
                       e->force_eos_step == p->force_eos_step;
@@ -686,7 +669,8 @@ extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_steps: not a decoder engine");
     if (!e->begun) return fail(WT_E_STATE, "wt_decoder_steps called before wt_decoder_begin");
     if (n_steps <= 0) return WT_OK;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     hipStream_t s = (hipStream_t)stream;
     if (e->profiling || !e->use_graph) {  // eager: per-kernel event timers need real launches
         for (int i = 0; i < n_steps; ++i) {
@@ -715,7 +699,8 @@ extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
 
 extern "C" int wt_decoder_poll(wt_engine* e, int* cur_len, int* n_unfinished, int* done, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER || !e->begun) return fail(WT_E_STATE, "wt_decoder_poll: no decode in flight");
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(e->h_state, e->st, sizeof(DecState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -729,7 +714,8 @@ extern "C" int wt_decoder_poll(wt_engine* e, int* cur_len, int* n_unfinished, in
 extern "C" int wt_decoder_read_ids(wt_engine* e, int32_t* ids_out, int ld, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER || !e->begun) return fail(WT_E_STATE, "wt_decoder_read_ids: no decode in flight");
     if (!ids_out || ld < e->max_length) return fail(WT_E_INVALID, "wt_decoder_read_ids: row stride %d < max_length %d", ld, e->max_length);
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     HIPCHK(hipMemcpy2DAsync(ids_out, (size_t)ld * 4, e->ids, (size_t)e->max_length * 4, (size_t)e->max_length * 4, e->B,
                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return WT_OK;
@@ -754,84 +740,17 @@ extern "C" int wt_decoder_greedy(wt_engine* e, const float* enc_hidden, int B, c
 }
 
 // ------------------------------------------------------------------------------------------------- Session surface
-static void set_desc(wt_tensor_desc* t, const char* name, int dtype, std::initializer_list<int64_t> shape) {
-    memset(t, 0, sizeof *t);
-    snprintf(t->name, sizeof t->name, "%s", name);
-    t->dtype = dtype;
-    t->ndim = (int)shape.size();
-    int k = 0;
-    for (int64_t s : shape) t->shape[k++] = s;
-}
-
 extern "C" int wt_engine_infer_shapes(wt_engine* e, const wt_tensor_desc* in, int n_in, wt_tensor_desc* out, int* n_out) {
-    if (!e || (!in && n_in) || !out || !n_out) return fail(WT_E_INVALID, "wt_engine_infer_shapes: null argument");
-    e->shapes_ok = false;
-    auto find = [&](const char* name) -> const wt_tensor_desc* {
-        for (int i = 0; i < n_in; ++i)
-            if (strncmp(in[i].name, name, WT_NAME_LEN) == 0) return &in[i];
-        return nullptr;
-    };
-    struct Spec { const char* name; int dtype; };
-    static const Spec enc_in[] = {{"data", WT_F32}, {"length", WT_F32}};
-    static const Spec dec_in[] = {{"data", WT_I32}, {"length", WT_I32}, {"encoder_hidden_states", WT_F32},
-                                  {"self_past_key", WT_F32}, {"self_past_value", WT_F32}, {"cross_past_key", WT_F32},
-                                  {"cross_past_value", WT_F32}, {"past_self_cache_mask", WT_F32}, {"past_cross_cache_mask", WT_F32}};
-    const Spec* specs = e->kind == WT_KIND_ENCODER ? enc_in : dec_in;
-    const int nspec = e->kind == WT_KIND_ENCODER ? 2 : 9;
-    for (int i = 0; i < n_in; ++i) {  // session.py:128-136: unknown name / wrong dtype -> error
-        const Spec* sp = nullptr;
-        for (int k = 0; k < nspec; ++k)
-            if (strncmp(in[i].name, specs[k].name, WT_NAME_LEN) == 0) sp = &specs[k];
-        if (!sp) return fail(WT_E_NOTFOUND, "Tensor:%s is not an input tensor", in[i].name);
-        if (sp->dtype != in[i].dtype) return fail(WT_E_INVALID, "Tensor:%s has wrong dtype", in[i].name);
-    }
-    auto shape_is = [](const wt_tensor_desc* t, std::initializer_list<int64_t> want) {
-        if (!t || t->ndim != (int)want.size()) return false;
-        int k = 0;
-        for (int64_t s : want) {
-            if (s >= 0 && t->shape[k] != s) return false;
-            ++k;
-        }
-        return true;
-    };
-    if (e->kind == WT_KIND_ENCODER) {
-        const wt_tensor_desc* data = find("data");
-        if (!shape_is(data, {-1, e->C, 2 * e->S}) || data->shape[0] < 1)
-            return fail(WT_E_INVALID, "encoder input 'data' must be f32 [B,%d,%d]", e->C, 2 * e->S);
-        if (*n_out < 1) return fail(WT_E_INVALID, "output descriptor capacity too small");
-        e->c_B = (int)data->shape[0];
-        set_desc(&out[0], "hidden_states", WT_F32, {data->shape[0], e->S, e->d});
-        *n_out = 1;
-        e->shapes_ok = true;
-        return WT_OK;
-    }
-    const int64_t L = e->L, H = e->H, S = e->S;
-    if (!shape_is(find("data"), {1, 1})) return fail(WT_E_INVALID, "decoder input 'data' must be i32 [1,1] (batch_size and id_len are fixed to 1, model.py:474-477)");
-    if (!shape_is(find("encoder_hidden_states"), {1, S, e->d})) return fail(WT_E_INVALID, "'encoder_hidden_states' must be f32 [1,%d,%d]", (int)S, e->d);
-    const wt_tensor_desc *spk = find("self_past_key"), *spv = find("self_past_value");
-    if (!shape_is(spk, {L, H, -1, HEAD_DIM}) || !shape_is(spv, {L, H, -1, HEAD_DIM}) || spk->shape[2] != spv->shape[2] ||
-        spk->shape[2] < 1 || spk->shape[2] > e->T + 1)
-        return fail(WT_E_INVALID, "'self_past_key/value' must be f32 [%d,%d,s,64] with 1 <= s <= %d", (int)L, (int)H, e->T + 1);
-    if (!shape_is(find("cross_past_key"), {L, H, S, HEAD_DIM}) || !shape_is(find("cross_past_value"), {L, H, S, HEAD_DIM}))
-        return fail(WT_E_INVALID, "'cross_past_key/value' must be f32 [%d,%d,%d,64]", (int)L, (int)H, (int)S);
-    const wt_tensor_desc *ms = find("past_self_cache_mask"), *mc = find("past_cross_cache_mask");
-    if (!ms || ms->ndim != 1 || ms->shape[0] < 1 || ms->shape[0] > e->T + 1)
-        return fail(WT_E_INVALID, "'past_self_cache_mask' must be f32 [m_s], 1 <= m_s <= %d", e->T + 1);
-    if (!mc || mc->ndim != 1 || mc->shape[0] < 1 || mc->shape[0] > S + 1)
-        return fail(WT_E_INVALID, "'past_cross_cache_mask' must be f32 [m_c], 1 <= m_c <= %d", (int)S + 1);
-    if (ms->shape[0] - 1 >= e->T) return fail(WT_E_INVALID, "position %d exceeds max_target_positions %d", (int)ms->shape[0] - 1, e->T);
-    if (*n_out < 5) return fail(WT_E_INVALID, "output descriptor capacity too small");
-    e->c_s = (int)spk->shape[2];
-    e->c_ms = (int)ms->shape[0];
-    e->c_mc = (int)mc->shape[0];
-    const int64_t cache_len = e->c_ms - 1 < e->c_s ? e->c_ms - 1 : e->c_s;  // model.py:278
-    set_desc(&out[0], "hidden_states", WT_F32, {1, 1, e->V});
-    set_desc(&out[1], "next_self_keys", WT_F32, {L, H, cache_len + 1, HEAD_DIM});
-    set_desc(&out[2], "next_self_values", WT_F32, {L, H, cache_len + 1, HEAD_DIM});
-    set_desc(&out[3], "next_cross_keys", WT_F32, {L, H, S, HEAD_DIM});
-    set_desc(&out[4], "next_cross_values", WT_F32, {L, H, S, HEAD_DIM});
-    *n_out = 5;
-    e->shapes_ok = true;
+    if (!e) return fail(WT_E_INVALID, "wt_engine_infer_shapes: null argument");
+    EngineDims dims;
+    dims.kind = e->kind; dims.precision = e->precision; dims.d = e->d; dims.H = e->H; dims.L = e->L; dims.F = e->F;
+    dims.C = e->C; dims.S = e->S; dims.T = e->T; dims.V = e->V;
+    ShapeState st;
+    char msg[400] = "";
+    const int rc = infer_shapes(dims, in, n_in, out, n_out, &st, msg, sizeof msg);  // host_logic.cpp
+    e->shapes_ok = st.ok;
+    if (rc) return fail(rc, "%s", msg);
+    e->c_B = st.c_B; e->c_s = st.c_s; e->c_ms = st.c_ms; e->c_mc = st.c_mc;
     return WT_OK;
 }
 
@@ -864,7 +783,8 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     float* ncv = (float*)get(out, n_out, "next_cross_values");
     if (!data || !enc || !spk || !spv || !cpk || !cpv || !logits || !nsk || !nsv || !nck || !ncv)
         return fail(WT_E_INVALID, "decoder run is missing a binding (need 7 input tensors besides the two masks and 5 outputs)");
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     int rc = dec_reserve(e, 1, e->T);
     if (rc) return rc;
     const int LH = e->L * e->H, S = e->S;
@@ -897,7 +817,8 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
 extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* avg_us, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER || !avg_us || iters < 1) return fail(WT_E_INVALID, "wt_decoder_time_cross_attention: bad arguments");
     if (!e->begun) return fail(WT_E_STATE, "wt_decoder_time_cross_attention needs a decode in flight (wt_decoder_begin)");
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
     hipStream_t s = (hipStream_t)stream;
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;

@@ -108,33 +108,38 @@ extern "C" int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int 
         npw < n_bins || (npw & 3))
         return wt_set_error(WT_E_INVALID, "wt_logmel_create: bad geometry (n_fft %d hop %d n_mels %d frames %d ndft %d npw %d)", n_fft, hop,
                             n_mels, n_frames, ndft, npw);
-    if (hipSetDevice(device) != hipSuccess) return wt_set_error(WT_E_HIP, "hipSetDevice(%d) failed", device);
+    wt::DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return wt_set_error(WT_E_HIP, "hipSetDevice(%d) failed", device);
     wt_logmel* h = new wt_logmel();
     h->device = device; h->n_fft = n_fft; h->hop = hop; h->n_mels = n_mels; h->n_frames = n_frames; h->n_bins = n_bins;
     h->n_samples = n_frames * hop; h->ndft = ndft; h->npw = npw;
     const size_t nd = (size_t)ndft * n_fft, nf = (size_t)n_mels * npw;
     if (hipMalloc((void**)&h->dft, nd * 4) != hipSuccess || hipMalloc((void**)&h->window, (size_t)n_fft * 4) != hipSuccess ||
         hipMalloc((void**)&h->filt, nf * 4) != hipSuccess) {
-        delete h;
+        wt_logmel_destroy(h);  // frees whichever tables were already allocated
         return wt_set_error(WT_E_NOMEM, "wt_logmel_create: table allocation failed");
     }
-    hipMemcpy(h->dft, dft, nd * 4, hipMemcpyHostToDevice);
-    hipMemcpy(h->window, window, (size_t)n_fft * 4, hipMemcpyHostToDevice);
-    hipMemcpy(h->filt, filters, nf * 4, hipMemcpyHostToDevice);
+    if (hipMemcpy(h->dft, dft, nd * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->window, window, (size_t)n_fft * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->filt, filters, nf * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        wt_logmel_destroy(h);
+        return wt_set_error(WT_E_HIP, "wt_logmel_create: table upload failed");
+    }
     *out = h;
     return WT_OK;
 }
 
 extern "C" void wt_logmel_destroy(wt_logmel* h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    wt::DeviceGuard guard(h->device);
     for (float* p : {h->dft, h->window, h->filt, h->frames}) if (p) hipFree(p);
     delete h;
 }
 
 extern "C" int wt_logmel_forward(wt_logmel* h, const float* audio, int batch, int n_in, float* mel_out, void* stream) {
     if (!h || !audio || !mel_out || batch < 1 || n_in < 1) return wt_set_error(WT_E_INVALID, "wt_logmel_forward: bad arguments");
-    if (hipSetDevice(h->device) != hipSuccess) return wt_set_error(WT_E_HIP, "hipSetDevice failed");
+    wt::DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return wt_set_error(WT_E_HIP, "hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
     const int T = h->n_frames;
     const size_t M = (size_t)batch * T;

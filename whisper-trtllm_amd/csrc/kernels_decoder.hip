@@ -404,15 +404,15 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
 template <int NB, int V, int NW>
 static hipError_t skinny_smem_attr() {
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
+    static PerDeviceFlag attr_set;
+    if (!attr_set.get() && smem > 48 * 1024) {
         for (const void* f : {reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true>),
                               reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false>),
                               reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        attr_set.set();
     }
     return hipSuccess;
 }

@@ -383,9 +383,9 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3) || p.c_rows_per_batch < 1 || p.a_rows_per_batch < 1) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;
     static int force_bk = 0;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<32>());
         if (e == hipSuccess)
@@ -394,7 +394,7 @@ hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         const char* ev = getenv("WT_GEMM_BK");
         force_bk = ev ? atoi(ev) : 0;
-        attr_set = true;
+        attr_set.set();
     }
     const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM;
     // measured (tools/microbench.py gemm, M=12000): BK=16 (41 KB of LDS, 128 VGPRs -> 3-4 resident blocks per CU, smaller idle
@@ -586,12 +586,12 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
 }
 
 hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceFlag attr_set;
+    if (!attr_set.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.set();
     }
     dim3 grid((S + FA_BQ - 1) / FA_BQ, H, B);
     hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(256), FA_SMEM, s, qkv, ctx, S, H);

@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256, HBK_ == 64 ? 2 : 3) void gemm_f16_kernel(const
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;
     static int bk = 32;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<64>());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<64>());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
@@ -259,7 +259,7 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
         if (e != hipSuccess) return e;
         const char* ev = getenv("WT_HGEMM_BK");
         if (ev && (atoi(ev) == 32 || atoi(ev) == 64)) bk = atoi(ev);
-        attr_set = true;
+        attr_set.set();
     }
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
     const dim3 grid(nbx * nby);

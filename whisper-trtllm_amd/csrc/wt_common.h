@@ -3,27 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "host_logic.h"  // HEAD_DIM, BlobHeader / BlobTensor, EngineDims (host-only part, also built under ASan/UBSan)
+
 namespace wt {
-
-constexpr int HEAD_DIM = 64;  // every Whisper size uses 64-wide heads (d_model / n_heads)
-
-// ---- serialized engine ("weight pack") layout, written by whisper-trtllm_amd/engine_pack.py -------------
-// [BlobHeader][BlobTensor * n_tensors][raw tensor bytes, each 256-byte aligned]
-struct BlobHeader {
-    char magic[8];  // "WTENGINE"
-    uint32_t version, kind, precision, n_tensors;
-    int32_t cfg[24];  // see CFG_* below
-    uint64_t table_off, data_off, total_bytes;
-};
-struct BlobTensor {
-    char name[96];
-    uint32_t dtype, ndim;
-    int64_t shape[4];
-    uint64_t offset, nbytes;  // offset from blob start
-};
-static_assert(sizeof(BlobHeader) == 144, "blob header layout");
-static_assert(sizeof(BlobTensor) == 152, "blob tensor layout");
-enum { CFG_D_MODEL = 0, CFG_HEADS, CFG_LAYERS, CFG_FFN, CFG_MELS, CFG_SRC_POS, CFG_TGT_POS, CFG_VOCAB, CFG_TIED };
 
 // ---- device-resident decode state: every per-step quantity kernels need lives here so that one captured
 // hipGraph replays for every step (nothing step-dependent is baked into kernel arguments) ------------------
@@ -104,6 +86,29 @@ struct DecAttnParams {
     const float* ln_h;     // [B][d] residual stream whose LayerNorm statistics normalise q
     const float* ln_r;     // [d] row sums of s.Wq.diag(gamma)
     const float* ln_t;     // [d] s.(Wq.beta + bq)
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property: a launcher keeps one "done" flag per device
+// (`static PerDeviceFlag f; if (!f.get()) { ...set...; f.set(); }`), so a second device opened in the same process gets
+// its dynamic-LDS limit raised too.
+struct PerDeviceFlag {
+    bool done[64] = {};
+    static int cur() { int dev = 0; (void)hipGetDevice(&dev); return dev & 63; }
+    bool get() const { return done[cur()]; }
+    void set() { done[cur()] = true; }
+};
+
+// Every ABI entry point runs on its handle's device and leaves the CALLER's current device (torch's) as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 // launchers (kernels_*.hip)
