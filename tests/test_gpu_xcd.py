@@ -67,7 +67,7 @@ def test_xcd_ffn(lib, B, d, Fd, n_parts):
         else:
             base, stride = hb, 0
         rc = lib.wt_dbg_xcd_ffn(P(base), stride, P(pbd), P(pin) if n_parts else None, n_parts, P(hx), P(lwd), P(lbd), P(W1d), P(b1d), P(W2d),
-                                P(fx), P(parts_out), P(st), P(sync), B, d, Fd, _stream())
+                                P(fx), P(parts_out), P(st), P(sync), None, B, d, Fd, _stream())
         assert rc == 0
         assert lib.wt_dbg_bump_step(P(st), _stream()) == 0
         torch.cuda.synchronize()

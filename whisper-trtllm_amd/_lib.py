@@ -110,7 +110,7 @@ def load():
     LL = ctypes.c_longlong
     lib.wt_dbg_xcd_census.argtypes = [P, I, P]
     lib.wt_dbg_bump_step.argtypes = [P, P]
-    lib.wt_dbg_xcd_ffn.argtypes = [P, LL, P, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, P]
+    lib.wt_dbg_xcd_ffn.argtypes = [P, LL, P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]
     if lib.wt_abi_version() != ABI_VERSION:
         raise EngineLibraryError(f"ABI version mismatch: library {lib.wt_abi_version()}, python {ABI_VERSION}")
     _lib = lib

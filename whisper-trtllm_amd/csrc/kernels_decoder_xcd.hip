@@ -87,6 +87,10 @@ __device__ __forceinline__ unsigned long long realtime() { return __builtin_amdg
 
 // All 32 workgroups of an XCD group meet here.  Precondition: nothing.  Postcondition: every plain store any of them issued
 // before the barrier is in the XCD's L2, i.e. visible to sc1 / nt loads of every other one.
+//
+// vmcnt counts loads and stores of a wave IN ORDER, so draining a wave's stores also waits for every load it issued earlier:
+// a wave that keeps weight loads in flight across the barrier must not store; the role-split kernels give all global stores and
+// waits to helper waves that never stream weights (the compute waves only execute the two workgroup barriers of this function).
 __device__ __forceinline__ void xcd_barrier(const XcdCtx& c, const int which) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave: its stores have been acknowledged by L2
     __syncthreads();
@@ -268,25 +272,28 @@ __device__ __forceinline__ void load_tile_a(WTileA& t, const float* W, const int
         }
     }
 }
-// acc[r][b] = partial dot products of tile row r with LDS activation row b (this lane's columns)
+// acc[r][b] = partial dot products of tile row r with LDS activation row b (this lane's columns).  One 256-column chunk at a
+// time with a compiler barrier in between: left alone, the scheduler hoists all 32 LDS reads (128 VGPRs) above the FMAs and
+// spills -- and a scratch reload is a vector-memory load that queues behind every weight load still in flight.
 __device__ __forceinline__ void tile_a_dot(const WTileA& t, const float (*xs)[1024], float (&acc)[RA][NBX]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int b = 0; b < NBX; ++b) {
-        float4 x[4];
+    for (int r = 0; r < RA; ++r)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) x[v] = *reinterpret_cast<const float4*>(&xs[b][4 * lane + 256 * v]);  // zero beyond d
+        for (int b = 0; b < NBX; ++b) acc[r][b] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float4 x[NBX];
+#pragma unroll
+        for (int b = 0; b < NBX; ++b) x[b] = *reinterpret_cast<const float4*>(&xs[b][4 * lane + 256 * v]);  // zero beyond d
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            f2v a2 = f2v{0.f, 0.f};
+            const float4 w = t.w[r][v];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float4 w = t.w[r][v];
-                a2 = __builtin_elementwise_fma(f2v{w.x, w.y}, f2v{x[v].x, x[v].y}, a2);
-                a2 = __builtin_elementwise_fma(f2v{w.z, w.w}, f2v{x[v].z, x[v].w}, a2);
-            }
-            acc[r][b] = a2[0] + a2[1];
+            for (int b = 0; b < NBX; ++b)
+                acc[r][b] = fmaf(w.x, x[b].x, fmaf(w.y, x[b].y, fmaf(w.z, x[b].z, fmaf(w.w, x[b].w, acc[r][b]))));
         }
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -295,6 +302,12 @@ __device__ __forceinline__ void tile_a_dot(const WTileA& t, const float (*xs)[10
 // =================================================================================================== K3: FFN
 // group g: fc1 rows [g*Fg, (g+1)*Fg) (Fg = F/8), slot j: ra = Fg/32 of them; then fc2 output rows [j*rb, (j+1)*rb) (rb = d/32)
 // over the K-slice [g*Fg, (g+1)*Fg) -> parts_out[g][b][m].
+#define XCD_STAMP(i)                                                                                 \
+    do {                                                                                             \
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = (long long)realtime(); \
+    } while (0)
+
+template <bool EARLY_W2>
 __global__ __launch_bounds__(256, 1) void xcd_ffn_kernel(const XcdFfnParams p) {
     extern __shared__ __attribute__((aligned(16))) float xsm[];
     float(*xs)[1024] = reinterpret_cast<float(*)[1024]>(xsm);  // [NBX][1024]
@@ -314,12 +327,32 @@ __global__ __launch_bounds__(256, 1) void xcd_ffn_kernel(const XcdFfnParams p) {
     const int rwa = (ra + 3) >> 2;                                  // rows per wave (last waves may have fewer / none)
     const int a_row0 = c.g * Fg + c.j * ra + wave * rwa;
     const int a_n = max(0, min(rwa, ra - wave * rwa));
+    XCD_STAMP(0);
     WTileA ta;
     load_tile_a(ta, p.W1, d, a_row0, a_n);
+    // ---- fc2 tile: rows [j*rb + wave*rwb, ..) x columns [g*Fg, +Fg)
+    const int rwb = (rb + 3) >> 2;
+    const int b_row0 = c.j * rb + wave * rwb;
+    const int b_n = max(0, min(rwb, rb - wave * rwb));
+    constexpr int RB = 8, VB = 2;                                    // rb <= 32 -> <= 8 rows per wave; Fg <= 512 -> 2 float4 per lane
+    float4 tb[RB][VB];
+    auto load_tb = [&]() {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int v = 0; v < VB; ++v) {
+                tb[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < b_n) tb[r][v] = ld_nt(p.W2 + (size_t)(b_row0 + r) * F + c.g * Fg + min(4 * lane + 256 * v, Fg - 4));
+            }
+    };
+    if (EARLY_W2) load_tb();   // all 128 KB of this workgroup's weights are in flight before anything else happens
     if (tid == 0) *s_dead = __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // an earlier launch gave up: do not wait
     prologue_reduce(p.pro, c, B, d);
+    XCD_STAMP(1);
     xcd_barrier(c, 0);
+    XCD_STAMP(2);
     prologue_layernorm(p.pro, c, B, d, xs);
+    XCD_STAMP(3);
     // ---- phase A: f[b][n] = GELU(W1[n] . LN(h[b]) + b1[n]) for my rows -> fx[g][b][n - g*Fg]
     float* fx = p.fx + (size_t)c.g * B * Fg;
     {
@@ -337,20 +370,10 @@ __global__ __launch_bounds__(256, 1) void xcd_ffn_kernel(const XcdFfnParams p) {
             }
         }
     }
-    // ---- fc2 tile: rows [j*rb + wave*rwb, ..) x columns [g*Fg, +Fg): requested before the barrier, lands while we wait
-    const int rwb = (rb + 3) >> 2;
-    const int b_row0 = c.j * rb + wave * rwb;
-    const int b_n = max(0, min(rwb, rb - wave * rwb));
-    constexpr int RB = 8, VB = 2;                                    // rb <= 32 -> <= 8 rows per wave; Fg <= 512 -> 2 float4 per lane
-    float4 tb[RB][VB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int v = 0; v < VB; ++v) {
-            tb[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < b_n) tb[r][v] = ld_nt(p.W2 + (size_t)(b_row0 + r) * F + c.g * Fg + min(4 * lane + 256 * v, Fg - 4));
-        }
+    XCD_STAMP(4);
+    if (!EARLY_W2) load_tb();  // requested before the barrier, lands while we wait
     xcd_barrier(c, 1);
+    XCD_STAMP(5);
     // ---- phase B: parts_out[g][b][m] = W2[m][slice] . f[b][slice]
     {
         float4 xf[NBX][VB];
@@ -364,6 +387,7 @@ __global__ __launch_bounds__(256, 1) void xcd_ffn_kernel(const XcdFfnParams p) {
 #pragma unroll
             for (int v = 0; v < VB; ++v)
                 if (4 * lane + 256 * v >= Fg || b >= B) xf[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        XCD_STAMP(6);
         float* po = p.parts_out + (size_t)c.g * B * d;
         const int rho = lane >> 4, li = lane & 15;
         const int my_r = rho >> 1, my_b = li + (rho & 1) * (NBX / 2);
@@ -386,6 +410,140 @@ __global__ __launch_bounds__(256, 1) void xcd_ffn_kernel(const XcdFfnParams p) {
             if (li < NBX / 2 && r < b_n && my_b < B) po[(size_t)my_b * d + b_row0 + r] = tot;
         }
     }
+    XCD_STAMP(7);
+}
+
+// Role-split form (the product): 8 waves.  Waves 0-3 = helpers: residual prologue, LayerNorm, every global store, every XCD
+// wait -- they never have weight loads outstanding, so their `vmcnt(0)` drains cost one L2 round trip.  Waves 4-7 = compute: they
+// request ALL their fc1 and fc2 weights (128 KB per workgroup at medium.en) in the first microsecond, then only consume LDS:
+// HBM streams from the first cycle of the launch to the last FMA while the helpers run the dependency chain beside it.
+// The two roles are separate code paths (registers are allocated per path) that execute the SAME number of workgroup barriers:
+//   S1 S2 = XCD barrier 0 | S3 = LayerNorm-ed rows in LDS | S4 = fc1 outputs in LDS | S5 S6 = XCD barrier 1 | S7 = f slice in LDS
+#define XCD_STAMP2(i)                                                                                                     \
+    do {                                                                                                                  \
+        if (p.stamps && (lane == 0) && (wave == 0 || wave == 4)) p.stamps[(size_t)blockIdx.x * 16 + (wave >> 2) * 8 + (i)] = (long long)realtime(); \
+    } while (0)
+
+__device__ __forceinline__ void ffn_helper_role(const XcdFfnParams& p, const XcdCtx& c, float (*xs)[1024], float (*fs2)[512], float* fs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = p.B, d = p.d, Fg = p.F / XCD_GROUPS, ra = Fg / XCD_SLOTS;
+    if (tid == 0) *c.s_dead = __hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // an earlier launch gave up: do not wait
+    prologue_reduce(p.pro, c, B, d);
+    XCD_STAMP2(1);
+    xcd_barrier(c, 0);                       // S1, S2
+    XCD_STAMP2(2);
+    prologue_layernorm(p.pro, c, B, d, xs);  // rows wave, wave+4 -> LDS; S3
+    XCD_STAMP2(3);
+    __syncthreads();                         // S4: the compute waves have left this workgroup's fc1 outputs in `fs`
+    XCD_STAMP2(4);
+    float* fx = p.fx + (size_t)c.g * B * Fg;
+    {
+        const int r = tid / NBX, b = tid % NBX;
+        if (r < ra && b < B) fx[(size_t)b * Fg + c.j * ra + r] = fs[r * NBX + b];
+    }
+    xcd_barrier(c, 1);                       // S5, S6
+    XCD_STAMP2(5);
+    for (int i = tid; i < NBX * (Fg >> 2); i += 256) {  // the slice f[b][g*Fg .. +Fg) of every batch row -> LDS
+        const int b = i / (Fg >> 2), c4 = i - b * (Fg >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) v = ld_sc1_f4(fx, (unsigned)(((size_t)b * Fg + 4 * c4) * 4));
+        *reinterpret_cast<float4*>(&fs2[b][4 * c4]) = v;
+    }
+    __syncthreads();                         // S7
+    XCD_STAMP2(6);
+}
+
+__device__ __forceinline__ void ffn_compute_role(const XcdFfnParams& p, const XcdCtx& c, float (*xs)[1024], float (*fs2)[512], float* fs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), cw = wave - 4;  // wave-uniform: SGPRs
+    const int B = p.B, d = p.d, F = p.F;
+    const int Fg = F / XCD_GROUPS, ra = Fg / XCD_SLOTS, rb = d / XCD_SLOTS;
+    const int rwa = (ra + 3) >> 2, rwb = (rb + 3) >> 2;
+    const int a_row0 = c.g * Fg + c.j * ra + cw * rwa, a_n = max(0, min(rwa, ra - cw * rwa));
+    const int b_row0 = c.j * rb + cw * rwb, b_n = max(0, min(rwb, rb - cw * rwb));
+    constexpr int RB = 8, VB = 2;   // rb <= 32 -> <= 8 fc2 rows per wave; Fg <= 512 -> 2 float4 per lane and row
+    // ---- every weight byte of this workgroup is requested now
+    WTileA ta;
+    load_tile_a(ta, p.W1, d, a_row0, a_n);
+    float4 tb[RB][VB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            tb[r][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < b_n) tb[r][v] = ld_nt(p.W2 + (size_t)(b_row0 + r) * F + c.g * Fg + min(4 * lane + 256 * v, Fg - 4));
+        }
+    XCD_STAMP2(1);
+    __syncthreads();  // S1
+    __syncthreads();  // S2
+    __syncthreads();  // S3: LayerNorm-ed rows are in LDS
+    XCD_STAMP2(3);
+    // ---- phase A: f[b][n] = GELU(W1[n] . LN(h[b]) + b1[n]) -> LDS
+    const int rho = lane >> 4, li = lane & 15;
+    const int my_r = rho >> 1, my_b = li + (rho & 1) * (NBX / 2);
+    {
+        float acc[RA][NBX];
+        tile_a_dot(ta, xs, acc);
+#pragma unroll
+        for (int pr = 0; pr < RA / 2; ++pr) {
+            const float tot = reduce_pair64<NBX>(acc[2 * pr], acc[2 * pr + 1]);
+            const int r = 2 * pr + my_r;
+            if (li < NBX / 2 && r < a_n) fs[(cw * rwa + r) * NBX + my_b] = gelu_erf_x(tot + p.b1[a_row0 + r]);
+        }
+    }
+    XCD_STAMP2(4);
+    __syncthreads();  // S4
+    __syncthreads();  // S5
+    __syncthreads();  // S6
+    __syncthreads();  // S7: this XCD's whole f slice is in LDS
+    XCD_STAMP2(6);
+    // ---- phase B: parts_out[g][b][m] = W2[m][slice] . f[b][slice]
+    float4 xf[NBX][VB];
+#pragma unroll
+    for (int b = 0; b < NBX; ++b)
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            const int col = 4 * lane + 256 * v;
+            xf[b][v] = col < Fg ? *reinterpret_cast<const float4*>(&fs2[b][col]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    float* po = p.parts_out + (size_t)c.g * B * d;
+#pragma unroll
+    for (int pr = 0; pr < RB / 2; ++pr) {
+        float a0[NBX], a1[NBX];
+#pragma unroll
+        for (int b = 0; b < NBX; ++b) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int v = 0; v < VB; ++v) {
+                s0 += dot4f(tb[2 * pr][v], xf[b][v]);
+                s1 += dot4f(tb[2 * pr + 1][v], xf[b][v]);
+            }
+            a0[b] = s0;
+            a1[b] = s1;
+        }
+        const float tot = reduce_pair64<NBX>(a0, a1);
+        const int r = 2 * pr + my_r;
+        if (li < NBX / 2 && r < b_n && my_b < B) po[(size_t)my_b * d + b_row0 + r] = tot;
+    }
+    XCD_STAMP2(7);
+}
+
+__global__ __launch_bounds__(512, 2) void xcd_ffn_rs_kernel(const XcdFfnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float xsm[];
+    float(*xs)[1024] = reinterpret_cast<float(*)[1024]>(xsm);                    // [NBX][1024] LayerNorm-ed residual rows
+    float(*fs2)[512] = reinterpret_cast<float(*)[512]>(xsm + NBX * 1024);        // [NBX][512]  this XCD's GELU(fc1) slice
+    float* fs = xsm + NBX * 1024 + NBX * 512;                                     // [16][NBX]   this workgroup's fc1 outputs
+    XcdCtx c;
+    c.g = blockIdx.x % XCD_GROUPS;
+    c.j = blockIdx.x / XCD_GROUPS;
+    c.xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID[3:0]
+    c.epoch = (unsigned)p.st->step + 1u;
+    c.sync = p.sync;
+    c.err = &p.st->xcd_err;
+    c.s_dead = reinterpret_cast<int*>(fs + 16 * NBX);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    XCD_STAMP2(0);
+    if (wave < 4) ffn_helper_role(p, c, xs, fs2, fs);
+    else ffn_compute_role(p, c, xs, fs2, fs);
 }
 
 hipError_t launch_xcd_ffn(const XcdFfnParams& p, hipStream_t s) {
@@ -394,11 +552,23 @@ hipError_t launch_xcd_ffn(const XcdFfnParams& p, hipStream_t s) {
     constexpr int smem = (NBX * 1024 + 4) * (int)sizeof(float);
     static PerDeviceFlag attr_set;
     if (!attr_set.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xcd_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(xcd_ffn_kernel<true>), reinterpret_cast<const void*>(xcd_ffn_kernel<false>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return e;
+        }
         attr_set.set();
     }
-    hipLaunchKernelGGL(xcd_ffn_kernel, dim3(XCD_BLOCKS), dim3(256), smem, s, p);
+    constexpr int smem_rs = (NBX * 1024 + NBX * 512 + 16 * NBX + 4) * (int)sizeof(float);
+    static PerDeviceFlag attr_rs;
+    if (!attr_rs.get()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xcd_ffn_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem_rs);
+        if (e != hipSuccess) return e;
+        attr_rs.set();
+    }
+    static const int variant = getenv("WT_XCD_FFN_VARIANT") ? atoi(getenv("WT_XCD_FFN_VARIANT")) : 2;
+    if (variant == 0) hipLaunchKernelGGL(xcd_ffn_kernel<false>, dim3(XCD_BLOCKS), dim3(256), smem, s, p);
+    else if (variant == 1) hipLaunchKernelGGL(xcd_ffn_kernel<true>, dim3(XCD_BLOCKS), dim3(256), smem, s, p);
+    else hipLaunchKernelGGL(xcd_ffn_rs_kernel, dim3(XCD_BLOCKS), dim3(512), smem_rs, s, p);
     return hipGetLastError();
 }
 

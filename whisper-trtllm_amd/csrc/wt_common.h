@@ -156,6 +156,7 @@ struct XcdFfnParams {
     float* parts_out;         // [8][B][d] fc2 partial sums of the 8 column slices
     DecState* st;
     unsigned* sync;           // XCD_SYNC_WORDS flag words of THIS kernel instance (zeroed at wt_decoder_begin)
+    long long* stamps;        // optional [256][16] s_memrealtime stamps (100 MHz) of thread 0 of every workgroup, or nullptr
     int B, d, F;
 };
 hipError_t launch_xcd_ffn(const XcdFfnParams& p, hipStream_t s);
