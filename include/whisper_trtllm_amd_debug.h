@@ -48,19 +48,6 @@ int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, co
                        void* stream);
 
 
-/* ---- XCD-fused decoder layer kernels (kernels_decoder_xcd.hip) ---- */
-/* out[b] = HW_REG_XCC_ID of the XCD workgroup b of a `blocks`-workgroup launch ran on */
-int wt_dbg_xcd_census(int* out, int blocks, void* stream);
-/* dec_state: int32[8] image of DecState (index 5 = step, 6 = xcd_err); step += 1 */
-int wt_dbg_bump_step(int* dec_state, void* stream);
-/* K3 of the fused layer: h = hbase + prev_bias + sum(parts_in) rebuilt into hx [8][B][d]; f = GELU(W1.LN(h) + b1) exchanged
- * inside each XCD through fx [8][B][F/8]; parts_out [8][B][d] = the 8 column-slice partial sums of W2.f (bias not added).
- * sync: XCD_SYNC_WORDS (768) unsigned flag words, zero before the first launch of an epoch (= dec_state step).
- * stamps: optional int64 [256][16] in-kernel s_memrealtime stamps (tools/microbench.py), or NULL. */
-int wt_dbg_xcd_ffn(const float* hbase, long long hbase_gstride, const float* prev_bias, const float* parts_in, int n_parts,
-                   float* hx, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, float* fx,
-                   float* parts_out, int* dec_state, unsigned* sync, long long* stamps, int B, int d, int F, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -169,62 +169,6 @@ def bench_dec_attn_resident(B=8, H=16, S=1500):
         print(f"dec_attn S={S} n_split=2, {L} rotating layer(s) ({L * 98} MB working set): {us:7.2f} us")
 
 
-def bench_xcd_ffn(B=8, d=1024, Fd=4096, L=24):
-    """K3 of the XCD-fused layer (one launch) against the classic fc1 + fc2 pair (two launches), 24 rotating weight sets."""
-    W1 = torch.randn(L, Fd, d, device="cuda") * 0.03
-    W2 = torch.randn(L, d, Fd, device="cuda") * 0.02
-    b1, b2 = torch.zeros(Fd, device="cuda"), torch.zeros(d, device="cuda")
-    g, be = torch.ones(d, device="cuda"), torch.zeros(d, device="cuda")
-    X = torch.randn(B, d, device="cuda")
-    Fb = torch.empty(B, Fd, device="cuda")
-    Y = torch.empty(B, d, device="cuda")
-
-    def classic(i):
-        lib.wt_dbg_skinny(P(X), P(g), P(be), P(W1[i]), P(b1), None, P(Fb), B, Fd, d, 5, 1, 1.0, ST())
-        lib.wt_dbg_skinny(P(Fb), None, None, P(W2[i]), P(b2), P(X), P(Y), B, d, Fd, 4, 0, 1.0, ST())
-    us = timeit(classic, L)
-    print(f"classic fc1 + fc2 (two launches): {us:7.2f} us per layer  {2 * Fd * d * 4 / us * 1e-6:6.2f} TB/s")
-    st = torch.zeros(8, dtype=torch.int32, device="cuda")
-    sync = torch.zeros(L, 768, dtype=torch.int32, device="cuda")
-    hx = torch.zeros(8, B, d, device="cuda")
-    parts = torch.zeros(2, 8, B, d, device="cuda")
-    fx = torch.empty(8, B, Fd // 8, device="cuda")
-    hx[:] = X
-
-    def fused(i):
-        lib.wt_dbg_xcd_ffn(P(hx), B * d, P(b2), P(parts[i & 1]), 8, P(hx), P(g), P(be), P(W1[i]), P(b1), P(W2[i]), P(fx), P(parts[(i + 1) & 1]),
-                           P(st), P(sync[i]), P(stamps[i]) if use_stamps else None, B, d, Fd, ST())
-        if i == L - 1:
-            lib.wt_dbg_bump_step(P(st), ST())
-    stamps = torch.zeros(L, 256, 16, dtype=torch.int64, device="cuda")
-    use_stamps = False
-    us = timeit(fused, L)
-    torch.cuda.synchronize()
-    print(f"XCD-fused FFN variant {os.environ.get('WT_XCD_FFN_VARIANT', '2')} (one launch, incl. 1/{L} step bump): {us:7.2f} us per layer  "
-          f"{2 * Fd * d * 4 / us * 1e-6:6.2f} TB/s   xcd_err={int(st[6])} step={int(st[5])}")
-    use_stamps = True
-    us = timeit(fused, L)
-    torch.cuda.synchronize()
-    variant = int(os.environ.get("WT_XCD_FFN_VARIANT", "2"))
-    t_all = stamps.cpu().double()                          # [L][256][16] in 10 ns ticks
-    t0 = t_all[:, :, 0].min(dim=1).values.view(-1, 1, 1)   # first workgroup start of each launch
-    rel = (t_all - t0) * 0.01                              # us since the launch's first workgroup started
-    print(f"  with stamps: {us:7.2f} us per layer; per stamp: median over launches of (min / median / max over workgroups), us")
-    if variant == 2:
-        rows = [(0, "H start"), (1, "H reduce done"), (2, "H xcd barrier 0"), (3, "H LN done (S3)"), (4, "H fc1 in LDS (S4)"), (5, "H xcd barrier 1"),
-                (6, "H f slice in LDS"), (8, "C start"), (9, "C loads issued"), (11, "C after S3"), (12, "C phase A done"), (14, "C after S7"), (15, "C end")]
-        end_col = 15
-    else:
-        rows = list(enumerate(["start", "reduce done", "barrier0", "LN done", "phaseA done", "barrier1", "f loaded", "end"]))
-        end_col = 7
-    for k, nme in rows:
-        r = rel[4:, :, k]
-        print(f"    {nme:20s} {r.min(1).values.median():6.2f} {r.median(1).values.median():6.2f} {r.max(1).values.median():6.2f}")
-    lay = t_all[4:, :, 0].min(1).values
-    print(f"  launch-to-launch start spacing (median): {((lay[1:] - lay[:-1]) * 0.01).median():6.2f} us; "
-          f"end(max) -> next start(min): {((lay[1:] - t_all[4:-1, :, end_col].max(1).values) * 0.01).median():6.2f} us")
-
-
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["dec_attn", "skinny", "gemm", "enc_attn"])

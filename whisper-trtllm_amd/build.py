@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwhisper_trtllm_amd.so")
-SOURCES = ["engine.hip", "host_logic.cpp", "frontend.hip", "debug_api.hip", "kernels_encoder.hip", "kernels_encoder_f16.hip", "kernels_decoder.hip", "kernels_decoder_xcd.hip"]
+SOURCES = ["engine.hip", "host_logic.cpp", "frontend.hip", "debug_api.hip", "kernels_encoder.hip", "kernels_encoder_f16.hip", "kernels_decoder.hip"]
 HEADERS = ["wt_common.h", "host_logic.h", os.path.join("..", "..", "include", "whisper_trtllm_amd.h"),
            os.path.join("..", "..", "include", "whisper_trtllm_amd_debug.h")]
 

@@ -90,18 +90,3 @@ extern "C" int wt_dbg_encoder_attention_f16(const void* qkv, void* ctx, int B, i
     return rc_of(launch_encoder_attention_f16(qkv, ctx, B, S, H, (hipStream_t)stream));
 }
 
-// ---- XCD-fused layer kernels (kernels_decoder_xcd.hip) ----
-extern "C" int wt_dbg_xcd_census(int* out, int blocks, void* stream) { return rc_of(launch_xcd_census(out, blocks, (hipStream_t)stream)); }
-extern "C" int wt_dbg_bump_step(int* dec_state, void* stream) {
-    return rc_of(launch_set_state_step_inc((DecState*)dec_state, (hipStream_t)stream));
-}
-extern "C" int wt_dbg_xcd_ffn(const float* hbase, long long hbase_gstride, const float* prev_bias, const float* parts_in, int n_parts,
-                              float* hx, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2, float* fx,
-                              float* parts_out, int* dec_state, unsigned* sync, long long* stamps, int B, int d, int F, void* stream) {
-    XcdFfnParams p;
-    memset(&p, 0, sizeof p);
-    p.pro.hbase = hbase; p.pro.hbase_gstride = hbase_gstride; p.pro.prev_bias = prev_bias; p.pro.parts_in = parts_in; p.pro.n_parts = n_parts;
-    p.pro.hx = hx; p.pro.ln_w = ln_w; p.pro.ln_b = ln_b;
-    p.W1 = W1; p.b1 = b1; p.W2 = W2; p.fx = fx; p.parts_out = parts_out; p.st = (DecState*)dec_state; p.sync = sync; p.stamps = stamps; p.B = B; p.d = d; p.F = F;
-    return rc_of(launch_xcd_ffn(p, (hipStream_t)stream));
-}

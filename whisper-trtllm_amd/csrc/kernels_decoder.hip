@@ -806,12 +806,6 @@ hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hi
     return hipGetLastError();
 }
 
-__global__ void step_inc_kernel(DecState* st) { st->step += 1; }
-hipError_t launch_set_state_step_inc(DecState* st, hipStream_t s) {
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, st);
-    return hipGetLastError();
-}
-
 // src [LH][src_rows][64] -> dst [LH][dst_rows][64], first n_rows rows of every (layer, head) slab
 __global__ __launch_bounds__(256) void copy_cache_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
                                                               int LH, int src_rows, int dst_rows, int n_rows) {

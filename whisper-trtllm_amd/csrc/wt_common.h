@@ -16,8 +16,7 @@ struct DecState {
     int done;          // stop test fired (all rows EOS, or cur_len >= max_length)
     int n_unfinished;  // rows that have not produced EOS yet
     int step;          // 0-based count of executed steps
-    int xcd_err;       // XCD-fused layer kernels (kernels_decoder_xcd.hip): 0, or XCD_ERR_* when a workgroup gave up an XCD-local wait
-    int pad1;
+    int pad0, pad1;
 };
 
 // ---- fp32 GEMM (encoder / cross-KV):  C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] ) ------------------
@@ -131,38 +130,6 @@ hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s);
 hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s);
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s);
 
-// ---- XCD-fused decoder layer (kernels_decoder_xcd.hip): 3 launches per layer, 256 workgroups = 8 XCD groups x 32 slots ----
-constexpr int XCD_GROUPS = 8, XCD_SLOTS = 32, XCD_BLOCKS = XCD_GROUPS * XCD_SLOTS;
-constexpr int XCD_BARRIERS = 3;                                     // XCD-local barriers per kernel instance (flag lines)
-constexpr int XCD_SYNC_WORDS = XCD_BARRIERS * XCD_GROUPS * XCD_SLOTS;  // unsigned words of flag memory per kernel instance
-constexpr int XCD_ERR_TIMEOUT = 1, XCD_ERR_PLACEMENT = 2;
-constexpr unsigned long long XCD_SPIN_TICKS = 200000;               // bounded spins: 2 ms of the 100 MHz s_memrealtime clock
-struct XcdPrologue {          // h = hbase + prev_bias + sum of the previous kernel's 8 partials, rebuilt per XCD group, then LayerNorm
-    const float* hbase;       // [B][d] (hbase_gstride == 0) or per-group copies [8][B][d] (may alias hx: in place)
-    long long hbase_gstride;
-    const float* prev_bias;   // [d] or nullptr
-    const float* parts_in;    // [n_parts][B][d]
-    int n_parts;              // 0 (layer input comes complete, e.g. the embedding) or 8
-    float* hx;                // [8][B][d] per-group copies of the rebuilt residual stream
-    const float* ln_w;        // LayerNorm gamma/beta [d]
-    const float* ln_b;
-};
-struct XcdFfnParams {
-    XcdPrologue pro;
-    const float* W1;          // [F][d]
-    const float* b1;          // [F]
-    const float* W2;          // [d][F]  (its bias is added by the NEXT kernel's prologue as prev_bias)
-    float* fx;                // [8][B][F/8] GELU(fc1) slices, exchanged inside each XCD
-    float* parts_out;         // [8][B][d] fc2 partial sums of the 8 column slices
-    DecState* st;
-    unsigned* sync;           // XCD_SYNC_WORDS flag words of THIS kernel instance (zeroed at wt_decoder_begin)
-    long long* stamps;        // optional [256][16] s_memrealtime stamps (100 MHz) of thread 0 of every workgroup, or nullptr
-    int B, d, F;
-};
-hipError_t launch_xcd_ffn(const XcdFfnParams& p, hipStream_t s);
-hipError_t launch_xcd_finish(const XcdPrologue& p, float* out, int B, int d, hipStream_t s);
-hipError_t launch_xcd_census(int* out, int blocks, hipStream_t s);
-
 struct SelectParams {
     const float* logits;   // [B][V]
     const uint8_t* mask;   // [V] bit0: always suppressed, bit1: suppressed when cur_len == begin_index
@@ -184,6 +151,5 @@ hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int m
 hipError_t launch_copy_cache_rows(const float* src, float* dst, int LH, int src_rows, int dst_rows, int n_rows,
                                   hipStream_t s);
 hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s);
-hipError_t launch_set_state_step_inc(DecState* st, hipStream_t s);  // tests / probes: st->step += 1
 
 }  // namespace wt
