@@ -210,11 +210,26 @@ def main():
         out["roofline_decode"] = {"bound": "hbm", "achieved": round(bytes_total / t_dec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(bytes_total / t_dec / 1e9 / HBM_PEAK_GBS, 4), "steps": n_steps,
                                   "ms_per_step": round(t_dec / n_steps * 1e3, 4), "bytes_per_step_avg": int(bytes_total / n_steps),
-                                  "launches_per_step": 7 * L + 3,
+                                  "launches_per_step": 7 * L + 2,
                                   "note": "all decoder steps of one batch, wall clock over the replayed step graphs"}
         vocab_bytes = V * d * 4
         out["roofline_vocab_proj"] = {"bound": "hbm", "achieved": round(vocab_bytes / (ms_vocab / max(1, n_vocab) * 1e-3) / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_us": round(ms_vocab / max(1, n_vocab) * 1e3, 2)}
+
+        # every launch kind of a decode step against the HBM roofline: algorithmic bytes of one launch / its graph-replayed average
+        # duration over the L layers' own weights (wt_decoder_time_kernel).  self_attn is timed at the current cache length.
+        Fd = cfg["decoder_ffn_dim"]
+        kinds = {"qkv": 3 * d * d * 4, "self_attn": B * H * n_steps * 64 * 4 * 2, "pair": 3 * d * d * 4, "cross_attn": bytes_cross,
+                 "cross_out": d * d * 4, "fc1": d * Fd * 4, "fc2": d * Fd * 4}
+        sk = {}
+        for kind, nbytes in kinds.items():
+            us = dec.time_kernel(kind, iters=20)
+            sk[kind] = {"bytes_per_launch": int(nbytes), "avg_launch_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
+                        "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+        sk["launch_time_sum_us_per_layer"] = round(sum(v["avg_launch_us"] for v in sk.values()), 2)
+        out["roofline_skinny"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_launch_kind": sk,
+                                  "note": "the 7 dependent launches of a decoder layer, each kind graph-replayed alone over all L layers "
+                                          f"(self_attn at cache length {n_steps}); a step = L x these + vocabulary projection + finish"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N = 1 only (the other ranks would idle behind it)
         # CPU baseline: the oracle (torch-CPU fp32 port of the reference's bundled HF path) on this box's host cores,

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """WER on a `librispeech.cache` of (log-mel [80,3000], text) pairs — the reference's examples/whisper/cal_wer.py flow
-(:249-287) on the batched fast path.  Needs real `whisper-*.en` engines and the cache produced by the reference's
-get_LibriSpeech.py; neither exists on the build/GPU boxes, so this script is exercised only by its unit-tested parts
-(tokenizer decode, English normaliser and WER: tests/test_text.py).
+(:249-287) on the batched fast path.  The cache comes from examples/whisper/get_LibriSpeech.py (this repo's, or the reference's:
+same format).  No LibriSpeech or `whisper-*.en` checkpoint exists on the build/GPU boxes, so the script is GPU-tested end to end
+on artefacts the tests write themselves (tests/test_gpu_session.py::test_cal_wer_script_end_to_end, also under torchrun with
+two ranks); the README WER table stays to be reproduced on a box that has the data.
+
+Multi-GPU (BASELINE config 5, utterances sharded over the GPUs of one node -- no collective on the data path):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/whisper/cal_wer.py ...
+every rank decodes a contiguous shard of the cache on its own GPU, hypotheses are gathered on the host, rank 0 prints the WER.
 
 The cache is a pickle (as in the reference): only load files you created yourself."""
 import argparse
@@ -39,7 +44,8 @@ def get_normalizer(whisper_dir):
 if __name__ == "__main__":
     args = parse_arguments()
     tensorrt_llm.logger.set_level(args.log_level)
-    torch.cuda.set_device(0)
+    rank, world, device, dist = tensorrt_llm.sharding.init_from_env()
+    torch.cuda.set_device(device)
     with open(os.path.join(args.engine_dir, "config.pkl"), "rb") as f:
         config = pickle.load(f)
     enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
@@ -47,13 +53,21 @@ if __name__ == "__main__":
     tok = WhisperTokenDecoder.from_dir(args.whisper)
     with open(args.cache, "rb") as f:
         dataset = pickle.load(f)
+    begin, end = tensorrt_llm.sharding.utterance_shard(len(dataset), world, rank)   # this rank's contiguous shard
     hypotheses, references = [], []
-    for i in range(0, len(dataset), args.batch):
-        chunk = dataset[i:i + args.batch]
+    for b0, b1 in tensorrt_llm.sharding.batches(begin, end, args.batch):
+        chunk = dataset[b0:b1]
         mel = torch.stack([torch.as_tensor(m, dtype=torch.float32) for m, _ in chunk]).cuda()
         ids = dec.generate(enc(mel)).cpu().tolist()
         hypotheses += tok.batch_decode(ids, skip_special_tokens=True)
         references += [t for _, t in chunk]
-    normalizer = get_normalizer(args.whisper)
-    wer = word_error_rate([normalizer(t) for t in references], [normalizer(t) for t in hypotheses])
-    print(f"WER: {wer * 100:.2f} %")
+    hypotheses = tensorrt_llm.sharding.gather_objects(hypotheses, dist)             # rank order == utterance order
+    references = tensorrt_llm.sharding.gather_objects(references, dist)
+    if rank == 0:
+        assert len(hypotheses) == len(dataset)
+        normalizer = get_normalizer(args.whisper)
+        wer = word_error_rate([normalizer(t) for t in references], [normalizer(t) for t in hypotheses])
+        print(f"WER: {wer * 100:.2f} %  ({len(dataset)} utterances, {world} rank(s))")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -7,7 +7,9 @@ Two decode paths over the same C-ABI:
   * fast path (default): resident in-place KV cache, on-device greedy loop, utterance batches of 8
     (`WhisperEncoderEngine` / `WhisperDecoderEngine`).
 Inputs: `--audio a.wav ...` (16 kHz mono; log-mel on the GPU front-end, transcripts printed when `--whisper` is a checkpoint
-directory with vocab.json) or, without audio on the box, `--synthetic N` seeded synthetic 80x3000 log-mels (outputs are token ids)."""
+directory with vocab.json) or, without audio on the box, `--synthetic N` seeded synthetic 80x3000 log-mels (outputs are token ids).
+Multi-GPU: under `python -m torch.distributed.run --nproc-per-node N ...` the fast path shards the utterances over the ranks
+(one process per GPU, full weight replica each, no data-path collective); ids are gathered on the host and rank 0 reports."""
 import argparse
 import os
 import pickle
@@ -35,11 +37,24 @@ def parse_arguments():
     parser.add_argument("--compare", action="store_true", help="also decode through the Session path and compare ids")
     parser.add_argument("--session", action="store_true", help="decode through the per-token Session protocol only")
     parser.add_argument("--synthetic", type=int, default=8, help="number of synthetic utterances")
+    parser.add_argument("--synthetic_start", type=int, default=0, help="index of the first synthetic utterance (synthetic.make_mel)")
     parser.add_argument("--audio", nargs="+", default=None, help="16 kHz mono audio files to transcribe instead (log-mel by the GPU "
                         "front-end, i.e. what hf_processor does in the reference, run.py:267); with --whisper <checkpoint dir> the ids "
                         "are also decoded to text (vocab.json)")
     parser.add_argument("--max_length", type=int, default=None)
+    parser.add_argument("--dump_ids", type=str, default=None, help="rank 0 writes the fast-path token ids as JSON (tests)")
     return parser.parse_args()
+
+
+def trim_after_eos(row, eos, pad):
+    """A batched fast-path row is padded with `pad` up to the longest row of its batch; a batch-1 Session row stops at its own EOS
+    (run.py:219-226).  Cut a row behind its first EOS so the two are comparable (pad == eos for the .en checkpoints)."""
+    row = list(row)
+    if eos in row[1:]:
+        row = row[:row.index(eos, 1) + 1]
+    while len(row) > 1 and row[-1] == pad and pad != eos:
+        row.pop()
+    return row
 
 
 class WhisperEncoder:
@@ -112,7 +127,10 @@ def decode_with_sessions(whisperencoder, whisperdecoder, config, mel):
 if __name__ == "__main__":
     args = parse_arguments()
     tensorrt_llm.logger.set_level(args.log_level)
-    torch.cuda.set_device(0)
+    rank, world, device, dist = tensorrt_llm.sharding.init_from_env()
+    torch.cuda.set_device(device)
+    if world > 1 and (args.session or args.compare):
+        raise SystemExit("the Session path is the reference's batch-1 single-GPU protocol: run --session / --compare without torchrun")
     with open(os.path.join(args.engine_dir, "config.pkl"), "rb") as f:
         config = pickle.load(f)
     if args.max_length:
@@ -128,20 +146,28 @@ if __name__ == "__main__":
             wav[j, :len(a)] = a
         mels = list(frontend(torch.from_numpy(wav).cuda()).split(1))
     else:
-        mels = [torch.from_numpy(tensorrt_llm.synthetic.make_mel(config, index=i, batch=1)).cuda() for i in range(args.synthetic)]
+        mels = [torch.from_numpy(tensorrt_llm.synthetic.make_mel(config, index=args.synthetic_start + i, batch=1)).cuda() for i in range(args.synthetic)]
     results = {}
     if not args.session:
         enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
         dec = tensorrt_llm.WhisperDecoderEngine(open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config)
+        begin, end = tensorrt_llm.sharding.utterance_shard(len(mels), world, rank)   # this rank's contiguous shard
         for _ in range(2):  # the first pass is the warm-up, as in run.py:260
+            if dist is not None:
+                dist.barrier()
             torch.cuda.synchronize()
             t0 = time.time()
             ids = []
-            for b0 in range(0, len(mels), 8):
-                ids += dec.generate(enc(torch.cat(mels[b0:b0 + 8]))).cpu().tolist()
+            for b0, b1 in tensorrt_llm.sharding.batches(begin, end, 8):
+                ids += dec.generate(enc(torch.cat(mels[b0:b1]))).cpu().tolist()
             torch.cuda.synchronize()
-            results["fast"] = (time.time() - t0, ids)
-        print(f"fast path   : {results['fast'][0]:.3f} s for {len(mels)} x 30 s  ({30 * len(mels) / results['fast'][0]:.1f} audio-s/s)")
+            elapsed = tensorrt_llm.sharding.max_over_ranks(time.time() - t0, dist)
+            results["fast"] = (elapsed, tensorrt_llm.sharding.gather_ids(ids, dist))
+        if rank == 0:
+            print(f"fast path   : {results['fast'][0]:.3f} s for {len(mels)} x 30 s on {world} rank(s)  ({30 * len(mels) / results['fast'][0]:.1f} audio-s/s)")
+            if args.dump_ids:
+                import json
+                json.dump(results["fast"][1], open(args.dump_ids, "w"))
     if args.session or args.compare:
         whisperencoder, whisperdecoder = WhisperEncoder(args, config), WhisperDecoder(args, config)
         for _ in range(2):
@@ -152,12 +178,18 @@ if __name__ == "__main__":
             results["session"] = (time.time() - t0, ids)
         print(f"Session path: {results['session'][0]:.3f} s for {len(mels)} x 30 s  ({30 * len(mels) / results['session'][0]:.1f} audio-s/s)")
     if args.compare:
-        a, b = results["fast"][1], results["session"][1]
+        eos, pad = config["eos_token_id"], config["pad_token_id"]
+        a = [trim_after_eos(r, eos, pad) for r in results["fast"][1]]
+        b = [trim_after_eos(r, eos, pad) for r in results["session"][1]]
         diff = [(x, y) for x, y in zip(a, b) if x != y]
         print(f"Compare Result: same [{len(a) - len(diff)}], diff [{len(diff)}]")
-    for key in results:
-        print(key, "ids[0][:16] =", results[key][1][0][:16])
-    if args.audio and os.path.isdir(args.whisper):   # batch_decode(predicted_ids, skip_special_tokens=True) of run.py:287
+    if rank == 0:
+        for key in results:
+            print(key, "ids[0][:16] =", results[key][1][0][:16])
+    if rank == 0 and args.audio and os.path.isdir(args.whisper):   # batch_decode(predicted_ids, skip_special_tokens=True) of run.py:287
         tok = tensorrt_llm.text.WhisperTokenDecoder.from_dir(args.whisper)
         for path, ids in zip(args.audio, next(iter(results.values()))[1]):
             print(f"{os.path.basename(path)}: {tok.decode(ids, skip_special_tokens=True)!r}")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -151,6 +151,10 @@ int wt_engine_get_timer(wt_engine* e, const char* which, wt_kernel_timer* out);
  * the L per-layer launches are captured into a hipGraph (as the decode step runs them), replayed `iters` times
  * between two hipEvents on the launch stream.  Needs a decode in flight (wt_decoder_begin).  Synchronises. */
 int wt_decoder_time_cross_attention(wt_engine* dec, int iters, float* avg_us, void* stream);
+/* the same for any of the seven per-layer launches of a decode step: which = "qkv" (LN + q|k|v GEMV + KV append), "self_attn",
+ * "pair" (self out-projection + folded cross query), "cross_attn", "cross_out" (split merge + cross out-projection), "fc1", "fc2".
+ * The residual stream is not advanced (every launch reads the buffers as they stand).  Synchronises. */
+int wt_decoder_time_kernel(wt_engine* dec, const char* which, int iters, float* avg_us, void* stream);
 
 /* ---- log-mel front-end: replaces the CPU numpy STFT inside the reference's timed loop,
  * `hf_processor(sample["array"], ...)` run.py:267 == WhisperFeatureExtractor._np_extract_fbank_features

@@ -300,3 +300,82 @@ def test_plain_c_host_of_the_c_abi(wt, tmp_path):
     want = z["ids"]
     np.testing.assert_array_equal(got, want[:, :got.shape[1]])
     assert got.shape[0] == want.shape[0] and (want[:, got.shape[1]:] == cfg["pad_token_id"]).all()
+
+
+def _write_engine_dir(wt, tmp_path, cfg, weights):
+    eng = tmp_path / "eng"
+    eng.mkdir()
+    (eng / "WhisperEncoder.engine").write_bytes(wt.convert.build_encoder_engine(cfg, weights))
+    (eng / "WhisperDecoder.engine").write_bytes(wt.convert.build_decoder_engine(cfg, weights))
+    (eng / "config.pkl").write_bytes(pickle.dumps(cfg))
+    return eng
+
+
+def _torchrun(nproc, script_args, timeout=600):
+    import subprocess
+    port = 29600 + os.getpid() % 300
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_two_ranks_decode_their_shards_through_the_hip_engine(wt, tmp_path):
+    """N > 1 on real hardware: two fresh processes (one per rank, both on this box's GPU -- LOCAL_RANK modulo the visible devices --
+    gloo for the barrier / max / gather, exactly the calls bench.py and the scripts make) each decode their `utterance_shard`
+    through WhisperEncoderEngine / WhisperDecoderEngine; the gathered ids must equal the single-process decode.  5 utterances over
+    2 ranks = shards of 3 and 2 (ragged); config 5's driver is this script under --nproc-per-node 8."""
+    import json
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")        # rows finish at different lengths (pad != eos)
+    eng = _write_engine_dir(wt, tmp_path, cfg, weights)
+    n, start = 5, 70
+    out = _torchrun(2, [os.path.join(ROOT, "examples", "whisper", "run.py"), "--engine_dir", str(eng), "--synthetic", str(n),
+                        "--synthetic_start", str(start), "--dump_ids", str(tmp_path / "ids.json")])
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "on 2 rank(s)" in out.stdout
+    got = json.load(open(tmp_path / "ids.json"))
+    enc = wt.WhisperEncoderEngine((eng / "WhisperEncoder.engine").read_bytes())
+    dec = wt.WhisperDecoderEngine((eng / "WhisperDecoder.engine").read_bytes(), cfg)
+    assert len(got) == n
+    for i in range(n):      # per utterance: a sharded batch pads to ITS batch's longest row, so compare up to the row's own end
+        one = dec.generate(enc(torch.from_numpy(wt.synthetic.make_mel(cfg, index=start + i, batch=1)).cuda())).cpu().tolist()[0]
+        assert got[i][:len(one)] == one and all(t == cfg["pad_token_id"] for t in got[i][len(one):]), (i, got[i], one)
+
+
+def test_cal_wer_under_torchrun_two_ranks(wt, tmp_path):
+    """examples/whisper/cal_wer.py with two ranks on one GPU gives the WER of the single-process run (hypotheses gathered in rank order)."""
+    import json
+    import subprocess
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    eng, ckpt = _write_engine_dir(wt, tmp_path, cfg, weights), tmp_path / "ckpt"
+    ckpt.mkdir()
+    _toy_vocabulary(cfg, ckpt)
+    mels = wt.synthetic.make_mel(cfg, index=70, batch=5)
+    refs = ["alpha beta", "gamma", "delta epsilon zeta", "eta", "theta iota"]
+    pickle.dump([(mels[i], refs[i]) for i in range(5)], open(tmp_path / "librispeech.cache", "wb"))
+    script = [os.path.join(ROOT, "examples", "whisper", "cal_wer.py"), "--whisper", str(ckpt), "--engine_dir", str(eng), "--cache",
+              str(tmp_path / "librispeech.cache"), "--batch", "2"]
+    single = subprocess.run([sys.executable] + script, capture_output=True, text=True, timeout=300)
+    assert single.returncode == 0, single.stderr[-2000:]
+    multi = _torchrun(2, script)
+    assert multi.returncode == 0, (multi.stdout[-1500:], multi.stderr[-3000:])
+    wer = lambda text: [ln for ln in text.splitlines() if ln.startswith("WER:")][-1].split()[1]
+    assert wer(single.stdout) == wer(multi.stdout) and "2 rank(s)" in multi.stdout
+
+
+def test_run_py_compare_ignores_batch_padding(wt, tmp_path):
+    """--compare: fast-path rows come from batches padded to the longest row, Session rows stop at their own EOS (batch 1, like the
+    reference's own compare): rows must be trimmed behind their first EOS before the comparison."""
+    import subprocess
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    eng = _write_engine_dir(wt, tmp_path, cfg, weights)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "whisper", "run.py"), "--engine_dir", str(eng), "--synthetic", "3",
+                          "--synthetic_start", str(int(z["mel_index"])), "--compare", "--dump_ids", str(tmp_path / "ids.json")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Compare Result: same [3], diff [0]" in out.stdout, out.stdout[-1500:]
+    import json
+    got = np.array(json.load(open(tmp_path / "ids.json")))
+    np.testing.assert_array_equal(got, z["ids"])          # and the fast path reproduces the reference-recorded golden (early-EOS row padded)

@@ -17,7 +17,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "wt_engine_open", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
     "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_read_ids",
-    "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention",
+    "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
 DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_f16", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_decode_attention",
@@ -95,6 +95,7 @@ def load():
     lib.wt_logmel_destroy.restype = None
     lib.wt_logmel_forward.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.wt_decoder_time_cross_attention.argtypes = [c_void_p, c_int, POINTER(c_float), c_void_p]
+    lib.wt_decoder_time_kernel.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_float), c_void_p]
     P, I, F = c_void_p, c_int, c_float
     lib.wt_dbg_gemm.argtypes = [P, I, P, P, P, P, I, I, I, I, P]
     lib.wt_dbg_gemm_f16.argtypes = [P, I, P, P, P, P, I, I, I, I, I, P]

@@ -141,6 +141,7 @@ static void timer_collect(EvTimer& t) {
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr int SEL_PARTS_CAP = 4096;  // partial (max, argmax) slots per batch row: >= workgroups of the vocabulary GEMV
 
 // ------------------------------------------------------------------------------------------------- open / close
 extern "C" int wt_abi_version(void) { return WT_ABI_VERSION; }
@@ -443,7 +444,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     const size_t o_sk = take(kv_self * 4), o_sv = take(kv_self * 4), o_ck = take(kv_cross * 4), o_cv = take(kv_cross * 4);
     const size_t o_h = take((size_t)B * d * 4), o_h2 = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
     const size_t o_cnt = take((size_t)B * e->H * 4);
-    const size_t o_selv = take((size_t)B * 8 * 4), o_seli = take((size_t)B * 8 * 4);
+    const size_t o_selv = take((size_t)B * SEL_PARTS_CAP * 4), o_seli = take((size_t)B * SEL_PARTS_CAP * 4);
     const size_t o_part = take((size_t)B * e->H * 16 * PART_STRIDE * 4), o_lg = take((size_t)B * e->V * 4);
     const size_t o_st = take(sizeof(DecState)), o_ids = take((size_t)B * cap_len * 4), o_unf = take((size_t)B * 4);
     const size_t o_forced = take((size_t)(cap_len + 1) * 4), o_mask = take((size_t)e->V);
@@ -483,75 +484,110 @@ struct StepIO {
     float* logits;                         // [B][V]
     int B, nsplit_self, nsplit_cross;
     bool embed;                            // launch the input-embedding kernel (the fast path gets it from greedy_finish)
+    // greedy fast path: masked argmax fused into the vocabulary GEMV (logits == nullptr: they never reach HBM unless traced)
+    const SelectParams* argmax;            // or nullptr: write plain logits
+    int* argmax_parts;                     // out: partial results per batch row (workgroups of the GEMV)
 };
 
-static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
+// The seven dependent launches of decoder layer i (model.py:321-369).  h = residual stream in, h1 = the other buffer of the
+// two-buffer stream (the layer's output ends up in h1).  `part` selects one launch: the decode step enqueues 0..6 in order,
+// wt_decoder_time_kernel replays one kind over all layers.
+enum { LP_QKV = 0, LP_SELF_ATTN, LP_PAIR, LP_CROSS_ATTN, LP_CROSS_OUT, LP_FC1, LP_FC2, LP_COUNT };
+static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, float* h1, int part, hipStream_t s) {
     static const bool defer = getenv("WT_NO_DEFER_MERGE") == nullptr;  // A/B switch
     const int d = e->d, B = io.B, H = e->H;
-    if (io.embed) LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
+    const DecLayerW& l = e->dec_layers[i];
+    float* sk = io.self_k + (size_t)i * B * H * io.self_cap * HEAD_DIM;
+    float* sv = io.self_v + (size_t)i * B * H * io.self_cap * HEAD_DIM;
+    const float* ck = io.cross_k + (size_t)i * B * H * e->S * HEAD_DIM;
+    const float* cv = io.cross_v + (size_t)i * B * H * e->S * HEAD_DIM;
     SkinnyParams k, k2;
     DecAttnParams a;
-    // The residual stream ping-pongs between two buffers once per layer: the self-attention out-projection (h1 = h + Wo.a)
-    // and the folded cross-attention query (which still reads h) share one launch, so h1 cannot overwrite h in place.
-    float *h = e->dh, *h1 = e->dh2;
-    for (int i = 0; i < e->L; ++i) {
-        const DecLayerW& l = e->dec_layers[i];
-        float* sk = io.self_k + (size_t)i * B * H * io.self_cap * HEAD_DIM;
-        float* sv = io.self_v + (size_t)i * B * H * io.self_cap * HEAD_DIM;
-        const float* ck = io.cross_k + (size_t)i * B * H * e->S * HEAD_DIM;
-        const float* cv = io.cross_v + (size_t)i * B * H * e->S * HEAD_DIM;
-        // --- self attention (model.py:273-281, 283-304): LN -> q|k|v, append k/v row in place, attend
-        memset(&k, 0, sizeof k);
+    memset(&k, 0, sizeof k);
+    memset(&k2, 0, sizeof k2);
+    memset(&a, 0, sizeof a);
+    switch (part) {
+    case LP_QKV:  // self attention (model.py:273-281, 283-304): LN -> q|k|v, append k/v row in place
         k.X = h; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
         k.Y = e->dq; k.kcache = sk; k.vcache = sv; k.st = e->st; k.B = B; k.N = 3 * d; k.K = d; k.ymode = YMODE_QKV_APPEND;
         k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = e->nt_loads;
         LAUNCH(launch_skinny(k, s));
-        memset(&a, 0, sizeof a);
+        break;
+    case LP_SELF_ATTN:
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
         a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads;
         LAUNCH(launch_dec_attn(a, s));
-        // --- ONE launch: out-projection + residual (h1 = h + Wo.a + bo) and the folded cross-attention query
-        //     u = s.Wq.diag(gamma2).(h + Wo.a + bo) = fold_w.[a ; h] + fold_c; LayerNorm statistics of h1 are applied
-        //     by the cross-attention kernel (model.py:261-272 semantics, one dependent launch fewer per layer)
-        memset(&k, 0, sizeof k);
+        break;
+    case LP_PAIR:
+        // ONE launch: out-projection + residual (h1 = h + Wo.a + bo) and the folded cross-attention query
+        // u = s.Wq.diag(gamma2).(h + Wo.a + bo) = fold_w.[a ; h] + fold_c; LayerNorm statistics of h1 are applied
+        // by the cross-attention kernel (model.py:261-272 semantics, one dependent launch fewer per layer)
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = h;
         k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
-        memset(&k2, 0, sizeof k2);
         k2.X = e->datt; k2.X2 = h; k2.xmode = XMODE_PLAIN; k2.x_direct = 1; k2.W = l.fold_w; k2.bias = l.fold_c;
         k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = e->nt_loads;
         LAUNCH(launch_skinny_pair(k, k2, s));
-        // --- cross attention over the encoder memory: K/V already resident
-        memset(&a, 0, sizeof a);
+        break;
+    case LP_CROSS_ATTN: {  // cross attention over the encoder memory: K/V already resident
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
         a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t;
         a.defer_merge = defer && io.nsplit_cross == 2;  // the out-projection below merges the two split partials while staging them
                                                         // (more splits, i.e. batch < 8: the attention kernel merges its own, by ticket)
-        {
-            hipEvent_t ta, tb;
-            timer_begin(e, e->t_cross, s, &ta, &tb);
-            LAUNCH(launch_dec_attn(a, s));
-            timer_end(e, e->t_cross, s, ta, tb);
-        }
-        memset(&k, 0, sizeof k);
+        hipEvent_t ta, tb;
+        timer_begin(e, e->t_cross, s, &ta, &tb);
+        LAUNCH(launch_dec_attn(a, s));
+        timer_end(e, e->t_cross, s, ta, tb);
+        break;
+    }
+    case LP_CROSS_OUT:
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = h1;
         k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         if (defer && io.nsplit_cross == 2) { k.parts = e->part; k.parts_nsplit = io.nsplit_cross; k.parts_H = H; }
         LAUNCH(launch_skinny(k, s));
-        // --- FFN (model.py:363-367)
-        memset(&k, 0, sizeof k);
+        break;
+    case LP_FC1:  // FFN (model.py:363-367)
         k.X = h1; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
         k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         LAUNCH(launch_skinny(k, s));
-        memset(&k, 0, sizeof k);
+        break;
+    case LP_FC2:
         k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = h1; k.Y = h1; k.st = e->st;
         k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         LAUNCH(launch_skinny(k, s));
+        break;
+    default:
+        return fail(WT_E_INVALID, "enqueue_layer_part: bad part %d", part);
+    }
+    return WT_OK;
+}
+
+static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
+    const int d = e->d, B = io.B;
+    if (io.embed) LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
+    SkinnyParams k;
+    // The residual stream ping-pongs between two buffers once per layer: the self-attention out-projection (h1 = h + Wo.a)
+    // and the folded cross-attention query (which still reads h) share one launch, so h1 cannot overwrite h in place.
+    float *h = e->dh, *h1 = e->dh2;
+    for (int i = 0; i < e->L; ++i) {
+        for (int part = 0; part < LP_COUNT; ++part) {
+            const int rc = enqueue_layer_part(e, io, i, h, h1, part, s);
+            if (rc) return rc;
+        }
         std::swap(h, h1);
     }
     // final LN + vocabulary projection (model.py:455-457; logits are the engine's 'hidden_states' output)
     memset(&k, 0, sizeof k);
     k.X = h; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
     k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
+    if (io.argmax) {  // Suppress -> SuppressAtBegin -> argmax in the epilogue (Force / pad / EOS rules: greedy_finish_kernel)
+        const SelectParams& sp = *io.argmax;
+        k.ymode = YMODE_ARGMAX; k.Y = nullptr; k.am_mask = sp.mask; k.am_val = sp.part_val; k.am_idx = sp.part_idx;
+        k.am_begin_index = sp.begin_index; k.am_trace = sp.trace; k.am_trace_steps = sp.max_length - 1;
+        const int grid = skinny_grid(k);
+        if (grid < 1 || grid > SEL_PARTS_CAP) return fail(WT_E_UNSUPPORTED, "vocabulary GEMV plan has %d workgroups (cap %d)", grid, SEL_PARTS_CAP);
+        k.am_ld = grid;
+        *io.argmax_parts = grid;
+    }
     {
         hipEvent_t ta, tb;
         timer_begin(e, e->t_skinny, s, &ta, &tb);
@@ -652,15 +688,20 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
     io.embed = false;  // dh already holds this step's input: written by wt_decoder_begin (step 0) or by the previous greedy_finish
-    int rc = enqueue_step(e, io, s);
-    if (rc) return rc;
+    static const bool fuse = getenv("WT_NO_FUSED_ARGMAX") == nullptr;  // A/B switch: logits to HBM + greedy_select_kernel
     SelectParams sp;
     memset(&sp, 0, sizeof sp);
     sp.logits = e->logits; sp.mask = e->mask; sp.forced = e->forced; sp.ids = e->ids; sp.unfinished = e->unfinished;
     sp.st = e->st; sp.trace = e->trace; sp.B = e->B; sp.V = e->V; sp.max_length = e->max_length;
     sp.begin_index = e->begin_index; sp.eos = e->eos; sp.pad = e->pad; sp.force_eos_step = e->force_eos_step;
     sp.part_val = e->sel_val; sp.part_idx = e->sel_idx; sp.tok_emb = e->tok_emb; sp.pos_emb = e->pos_emb; sp.next_x = e->dh;
-    sp.d_model = e->d;
+    sp.d_model = e->d; sp.n_parts = 8; sp.fused = 0;
+    int parts = 0;
+    io.argmax = fuse ? &sp : nullptr;
+    io.argmax_parts = &parts;
+    int rc = enqueue_step(e, io, s);
+    if (rc) return rc;
+    if (fuse) { sp.fused = 1; sp.n_parts = parts; }
     LAUNCH(launch_greedy_select(sp, s));
     return WT_OK;
 }
@@ -805,6 +846,7 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1;
     io.nsplit_self = 1; io.nsplit_cross = pick_splits(1, e->H, S);
     io.embed = true;
+    io.argmax = nullptr; io.argmax_parts = nullptr;
     e->begun = false;  // the resident greedy state is clobbered by this call
     return enqueue_step(e, io, s);
 }
@@ -842,6 +884,54 @@ extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* a
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
     HIPCHK(hipGraphLaunch(ge, s));  // warm-up replay (replayed on the caller's stream, like the decode step)
+    HIPCHK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(ge, s));
+    HIPCHK(hipEventRecord(b, s));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *avg_us = ms * 1e3f / ((float)iters * e->L);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    return WT_OK;
+}
+
+// Average launch time (us) of ONE kind of decode-step launch (LP_* above), measured like wt_decoder_time_cross_attention: the L
+// per-layer launches of that kind (each layer's own weights / caches, so nothing is cache-resident that would not be in the real
+// step) are captured into a hipGraph and replayed `iters` times between two hipEvents.  The residual stream is not advanced:
+// every launch reads the current buffers, which is what its duration depends on.
+extern "C" int wt_decoder_time_kernel(wt_engine* e, const char* which, int iters, float* avg_us, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER || !which || !avg_us || iters < 1) return fail(WT_E_INVALID, "wt_decoder_time_kernel: bad arguments");
+    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_time_kernel needs a decode in flight (wt_decoder_begin)");
+    static const char* names[LP_COUNT] = {"qkv", "self_attn", "pair", "cross_attn", "cross_out", "fc1", "fc2"};
+    int part = -1;
+    for (int i = 0; i < LP_COUNT; ++i)
+        if (!strcmp(which, names[i])) part = i;
+    if (part < 0) return fail(WT_E_NOTFOUND, "unknown decode kernel '%s' (qkv, self_attn, pair, cross_attn, cross_out, fc1, fc2)", which);
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    hipStream_t s = (hipStream_t)stream;
+    StepIO io;
+    io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
+    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
+    io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross; io.embed = false; io.argmax = nullptr; io.argmax_parts = nullptr;
+    const bool was_profiling = e->profiling;
+    e->profiling = false;  // no event records inside the capture
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+    int rc = WT_OK;
+    for (int i = 0; i < e->L && rc == WT_OK; ++i) rc = enqueue_layer_part(e, io, i, e->dh, e->dh2, part, e->own_stream);
+    hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
+    e->profiling = was_profiling;
+    if (rc != WT_OK || ce != hipSuccess) return fail(WT_E_HIP, "capturing the timing graph of '%s' failed", which);
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipGraphLaunch(ge, s));  // warm-up replay
     HIPCHK(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(ge, s));
     HIPCHK(hipEventRecord(b, s));

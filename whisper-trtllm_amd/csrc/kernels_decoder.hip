@@ -127,7 +127,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         if (p.bias) bias_pf = p.bias[n_pf];
         if (p.ymode == YMODE_PLAIN) {
             if (p.resid) resid_pf = p.resid[(size_t)b_pf * p.N + n_pf];
-        } else {
+        } else if (p.ymode == YMODE_QKV_APPEND) {
             self_len_pf = p.st->self_len;
         }
     }
@@ -270,6 +270,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 if (!kok[v] || b >= p.B) xr[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    // YMODE_ARGMAX: running masked maximum of the rows this lane finishes (rows ascend, so the lowest index wins ties)
+    float am_best = -INFINITY;
+    int am_bidx = 0x7fffffff;
+    const bool am_at_begin = p.ymode == YMODE_ARGMAX && p.st->cur_len == p.am_begin_index;
+    float* am_tr = (p.ymode == YMODE_ARGMAX && p.am_trace) ? p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N : nullptr;
     const int niter = (rows_per_group + 1) / 2;  // identical for every wave of the block (barriers below)
     // one iteration = two W rows; `cur` (static) is the register buffer holding them, the other one is prefetched
     auto body = [&](auto cur_c, const int it) {
@@ -336,6 +341,15 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 const size_t off = (size_t)my_b * p.N + n;
                 if (p.resid) v += it == 0 ? resid_pf : p.resid[off];
                 p.Y[off] = v;
+            } else if (p.ymode == YMODE_ARGMAX) {  // logits processors (Suppress -> SuppressAtBegin) + running argmax, logits_process.py:1281-1311
+                v *= p.q_scale;
+                if (am_tr) am_tr[n] = v;
+                const uint8_t mk = p.am_mask[n];
+                if ((mk & 1) || ((mk & 2) && am_at_begin)) v = -INFINITY;
+                if (v > am_best || (v == am_best && n < am_bidx)) {
+                    am_best = v;
+                    am_bidx = n;
+                }
             } else {  // fused q|k|v projection: q (scaled) -> Y, k/v rows appended in place at index self_len
                 const int third = n / p.d_model, nn = n - third * p.d_model;
                 if (third == 0) {
@@ -351,6 +365,32 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     for (int it = 0; it < niter; it += 2) {
         body(std::integral_constant<int, 0>{}, it);
         if (it + 1 < niter) body(std::integral_constant<int, 1>{}, it + 1);
+    }
+    if (p.ymode == YMODE_ARGMAX) {
+        // one (max, argmax) per batch row and workgroup: output lanes -> LDS (the activation staging area is free by now) ->
+        // thread b scans the NW x 2 candidates of batch row b in a fixed order
+        __syncthreads();
+        float* cv = sk_smem;                                 // [NW][2][NB]
+        int* ci = reinterpret_cast<int*>(sk_smem + NW * 2 * NB);
+        if (is_out_lane) {
+            cv[(wave * 2 + my_r) * NB + my_b] = am_best;
+            ci[(wave * 2 + my_r) * NB + my_b] = am_bidx;
+        }
+        __syncthreads();
+        if (tid < p.B) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+            for (int i = 0; i < NW * 2; ++i) {
+                const float v = cv[i * NB + tid];
+                const int ix = ci[i * NB + tid];
+                if (v > best || (v == best && ix < bidx)) {
+                    best = v;
+                    bidx = ix;
+                }
+            }
+            p.am_val[(size_t)tid * p.am_ld + block] = best;
+            p.am_idx[(size_t)tid * p.am_ld + block] = bidx;
+        }
     }
 }
 
@@ -441,8 +481,16 @@ static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, 
     return hipGetLastError();
 }
 
+int skinny_grid(const SkinnyParams& p) {  // workgroups launch_skinny will use for p (the column count of am_val / am_idx)
+    SkinnyPlan pl;
+    hipError_t e = p.B <= 2 ? skinny_plan<2, 4, 4>(p, &pl) : p.B <= 4 ? skinny_plan<4, 4, 4>(p, &pl) : p.B <= 8 ? skinny_plan<8, 4, 4>(p, &pl)
+                                                                                                   : skinny_plan<16, 2, 8>(p, &pl);
+    return e == hipSuccess ? pl.grid : -1;
+}
+
 hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
     if (p.B < 1 || p.B > 16 || (p.K & 3)) return hipErrorInvalidValue;
+    if (p.ymode == YMODE_ARGMAX && (!p.am_mask || !p.am_val || !p.am_idx || p.am_ld < skinny_grid(p) || p.resid || p.act)) return hipErrorInvalidValue;
     if (p.B <= 2) return skinny_launch_cfg<2, 4, 4>(p, s);
     if (p.B <= 4) return skinny_launch_cfg<4, 4, 4>(p, s);
     if (p.B <= 8) return skinny_launch_cfg<8, 4, 4>(p, s);
@@ -720,30 +768,53 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
 __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p) {
     __shared__ int s_tok[16];
     __shared__ int s_pos;
+    __shared__ float s_wv[4];
+    __shared__ int s_wi[4];
     DecState* st = p.st;
     if (st->done) return;
     const int tid = threadIdx.x, cur_len = st->cur_len, step = st->step;
-    if (tid < p.B) {
-        const int b = tid;
-        float best = p.part_val[b * SELECT_CHUNKS];
-        int bidx = p.part_idx[b * SELECT_CHUNKS];
-        for (int c = 1; c < SELECT_CHUNKS; ++c) {  // chunks are in increasing index order: strict > keeps the lowest index on ties
-            const float v = p.part_val[b * SELECT_CHUNKS + c];
-            if (v > best) {
+    for (int b = 0; b < p.B; ++b) {  // final masked argmax of row b over the n_parts partial results (lowest index on ties)
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        for (int i = tid; i < p.n_parts; i += 256) {
+            const float v = p.part_val[(size_t)b * p.n_parts + i];
+            const int ix = p.part_idx[(size_t)b * p.n_parts + i];
+            if (v > best || (v == best && ix < bidx)) {
                 best = v;
-                bidx = p.part_idx[b * SELECT_CHUNKS + c];
+                bidx = ix;
             }
         }
-        int tok = bidx;
-        const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
-        if (forced >= 0) tok = forced;
-        if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
-        if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
-        p.ids[(size_t)b * p.max_length + cur_len] = tok;
-        if (tok == p.eos) p.unfinished[b] = 0;
-        s_tok[b] = tok;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ov > best || (ov == best && oi < bidx)) {
+                best = ov;
+                bidx = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            s_wv[tid >> 6] = best;
+            s_wi[tid >> 6] = bidx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 4; ++i)
+                if (s_wv[i] > best || (s_wv[i] == best && s_wi[i] < bidx)) {
+                    best = s_wv[i];
+                    bidx = s_wi[i];
+                }
+            int tok = bidx;
+            const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
+            if (forced >= 0) tok = forced;
+            if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
+            if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
+            p.ids[(size_t)b * p.max_length + cur_len] = tok;
+            if (tok == p.eos) p.unfinished[b] = 0;
+            s_tok[b] = tok;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid == 0) {
         int nu = 0;
         for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
@@ -767,8 +838,8 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
     }
 }
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s) {
-    if (p.B > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(greedy_select_kernel, dim3(SELECT_CHUNKS, p.B), dim3(256), 0, s, p);
+    if (p.B > 16 || p.n_parts < 1 || (!p.fused && p.n_parts != SELECT_CHUNKS)) return hipErrorInvalidValue;
+    if (!p.fused) hipLaunchKernelGGL(greedy_select_kernel, dim3(SELECT_CHUNKS, p.B), dim3(256), 0, s, p);  // else: done by the vocabulary GEMV
     hipLaunchKernelGGL(greedy_finish_kernel, dim3(1), dim3(256), 0, s, p);
     return hipGetLastError();
 }

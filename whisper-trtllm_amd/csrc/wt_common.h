@@ -41,7 +41,7 @@ constexpr int PART_STRIDE = 68;  // attention split partial: o[64], m, l, 2 pad 
 
 // ---- decode-step skinny GEMM:  y[b][n] = epi( sum_k X(b)[k] * W[n][k] + bias[n] ),  b < NB <= 8 -----------
 enum { XMODE_PLAIN = 0, XMODE_LAYERNORM = 1 };
-enum { YMODE_PLAIN = 0, YMODE_QKV_APPEND = 1 };
+enum { YMODE_PLAIN = 0, YMODE_QKV_APPEND = 1, YMODE_ARGMAX = 2 };
 struct SkinnyParams {
     const float* X;        // [B][K]  (with X2: [B][K/2], columns [0, K/2))
     const float* parts;    // optional: X is the MERGE of attention split partials [B][parts_H][parts_nsplit][PART_STRIDE] (o[64], m, l)
@@ -65,6 +65,13 @@ struct SkinnyParams {
     int d_model, s_cap;    // QKV_APPEND
     float q_scale;         // QKV_APPEND: multiply the q third by this (head_dim^-0.5)
     int parts_nsplit, parts_H;
+    // YMODE_ARGMAX (vocabulary projection of the greedy fast path): the logits never reach HBM unless a trace is requested.
+    // Every workgroup reduces its rows to one masked (max, argmax) per batch row: am_val / am_idx [B][am_ld], column = workgroup.
+    const uint8_t* am_mask;  // [N] bit0: always suppressed, bit1: suppressed when cur_len == am_begin_index
+    float* am_val;
+    int* am_idx;
+    float* am_trace;       // optional raw-logits trace [B][am_trace_steps][N] (row st->step), or nullptr
+    int am_ld, am_begin_index, am_trace_steps;
 };
 
 // ---- decode attention (query length 1), split over the key axis ---------------------------------------------
@@ -126,6 +133,7 @@ hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S
 hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
                             int d, const DecState* st, hipStream_t s);
 hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s);
+int skinny_grid(const SkinnyParams& p);  // workgroups launch_skinny uses for p (column count of am_val / am_idx), -1 if p is invalid
 // two independent skinny GEMMs (same batch) in ONE launch: blocks [0, grid_a) run `a`, the rest run `b`
 hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s);
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s);
@@ -138,8 +146,9 @@ struct SelectParams {
     int* unfinished;       // [B]
     DecState* st;
     float* trace;          // optional [B][max_length-1][V]
-    float* part_val;       // scratch [B][8] partial maxima
-    int* part_idx;         // scratch [B][8]
+    float* part_val;       // scratch [B][n_parts] partial maxima (n_parts = 8 chunks of greedy_select_kernel, or the workgroups
+    int* part_idx;         //   of the vocabulary GEMV when the argmax is fused into its epilogue: fused != 0)
+    int n_parts, fused;
     const float* tok_emb;  // next-step embedding: embed_tokens [V][d], embed_positions [T][d]
     const float* pos_emb;
     float* next_x;         // [B][d] decoder input of the next step, or nullptr

@@ -264,6 +264,16 @@ class WhisperDecoderEngine:
                                                                       ctypes.c_void_p(stream)), "wt_decoder_time_cross_attention")
         return float(us.value)
 
+    def time_kernel(self, which: str, iters: int = 20) -> float:
+        """Average launch time (us) of one kind of per-layer decode launch ("qkv", "self_attn", "pair", "cross_attn", "cross_out",
+        "fc1", "fc2"), graph-replayed over all layers' own weights and caches."""
+        import torch
+        us = ctypes.c_float()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_time_kernel(self.session.handle, which.encode(), iters, ctypes.byref(us),
+                                                             ctypes.c_void_p(stream)), "wt_decoder_time_kernel")
+        return float(us.value)
+
     def timer(self, which: str):
         t = _lib.KernelTimer()
         _lib.check(self.session._lib.wt_engine_get_timer(self.session.handle, which.encode(), ctypes.byref(t)), "wt_engine_get_timer")

@@ -40,3 +40,41 @@ def gather_ids(local_ids: Sequence[Sequence[int]], dist=None) -> List[List[int]]
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, rows)
     return [r for part in out for r in part]
+
+
+def init_from_env(backend: str = None):
+    """One process per GPU under `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env).
+
+    Returns (rank, world, device_index, dist_or_None).  Without those variables: (0, 1, 0, None) -- a plain single-process run.
+    Device = LOCAL_RANK modulo the visible GPUs, so a one-GPU box can rehearse N ranks on its one card.  Backend: "nccl"
+    (= RCCL) when every rank has its own GPU, else "gloo" (RCCL cannot put two ranks on one device); the collectives here only
+    carry a barrier, one float64 and the token-id lists, never activations."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or "RANK" not in os.environ:
+        return 0, 1, 0, None
+    import torch
+    import torch.distributed as dist
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("whisper-trtllm_amd has no CPU fallback: no GPU is visible to this rank")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    device = local % ndev
+    if backend is None:
+        backend = "nccl" if ndev >= local_world else "gloo"
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        kw = {"device_id": torch.device("cuda", device)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, device, dist
+
+
+def gather_objects(local: list, dist=None) -> list:
+    """Concatenate every rank's list in rank order (host-side; hypotheses / references / id rows)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(local)
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, list(local))
+    return [x for part in out for x in part]
