@@ -53,7 +53,8 @@ def test_gemm(lib, M, N, K, act, use_res):
 
 @pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
     (128, 128, 64, 0, 0, False), (200, 136, 240, 1, 1, False), (1500, 384, 384, 0, 0, True), (97, 1000, 1536, 1, 1, False),
-    (3000, 128, 240, 1, 1, False), (33, 51, 8, 0, 0, False), (1024, 3072, 1024, 0, 0, True)])
+    (3000, 128, 240, 1, 1, False), (33, 51, 8, 0, 0, False), (1024, 3072, 1024, 0, 0, True),
+    (130, 70, 64, 0, 0, False), (257, 129, 128, 1, 1, False), (1500, 1024, 4096, 0, 0, True), (3000, 1024, 3072, 1, 0, False)])   # LDS-DMA kernel: ragged M/N tiles, 1..64 K-tiles
 def test_gemm_f16(lib, M, N, K, act, out_half, use_res):
     A, W, b = _rand(M, K, seed=1).half(), _rand(N, K, seed=2, scale=K ** -0.5).half(), _rand(N, seed=3)
     R = _rand(M, N, seed=4) if use_res else None
@@ -73,8 +74,8 @@ def test_gemm_f16(lib, M, N, K, act, out_half, use_res):
     assert err < tol, err
 
 
-def test_gemm_f16_identity_asymmetric(lib):
-    n = 160
+@pytest.mark.parametrize("n", [160, 192, 256])   # 192, 256: K % 64 == 0 -> the LDS-DMA kernel (swizzled unpadded tiles)
+def test_gemm_f16_identity_asymmetric(lib, n):
     A = torch.eye(n).half()
     W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 / 8.0).half()
     C = torch.empty(n, n, device="cuda")

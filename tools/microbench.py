@@ -119,7 +119,12 @@ def bench_gemm_fixed(M=12000, N=1024):
         print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
-def bench_gemm_f16(M=12000):
+def bench_gemm_f16(M=None):
+    for m in ([M] if M else [12000, 24000]):
+        _bench_gemm_f16(m)
+
+
+def _bench_gemm_f16(M):
     for (N, K, act, oh) in ((3072, 1024, 0, 0), (1024, 1024, 0, 0), (4096, 1024, 1, 1), (1024, 4096, 0, 0), (1024, 3072, 1, 0)):
         A = torch.randn(M, K, device="cuda").half()
         W = (torch.randn(4, N, K, device="cuda") * 0.03).half()

@@ -273,6 +273,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     // YMODE_ARGMAX: running masked maximum of the rows this lane finishes (rows ascend, so the lowest index wins ties)
     float am_best = -INFINITY;
     int am_bidx = 0x7fffffff;
+    uint8_t am_mk[2] = {0, 0};  // mask bytes of this lane's rows, requested one iteration ahead with the weights (a load in the
+                                // epilogue would be an exposed L2 round trip per row pair: measured +10 us on the 51864-row GEMV)
+    if (p.ymode == YMODE_ARGMAX) am_mk[0] = p.am_mask[min(row_begin + my_r, p.N - 1)];
     const bool am_at_begin = p.ymode == YMODE_ARGMAX && p.st->cur_len == p.am_begin_index;
     float* am_tr = (p.ymode == YMODE_ARGMAX && p.am_trace) ? p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N : nullptr;
     const int niter = (rows_per_group + 1) / 2;  // identical for every wave of the block (barriers below)
@@ -281,7 +284,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         constexpr int cur = decltype(cur_c)::value;
         const int row = row_begin + 2 * it;
         const bool active = row < row_end;
-        if (active && row + 2 < row_end) wload(cur ^ 1, row + 2);
+        if (active && row + 2 < row_end) {
+            wload(cur ^ 1, row + 2);
+            if (p.ymode == YMODE_ARGMAX) am_mk[cur ^ 1] = p.am_mask[min(row + 2 + my_r, p.N - 1)];
+        }
         float out = 0.f;
         if (active) {
             float acc[2][NB];
@@ -344,7 +350,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             } else if (p.ymode == YMODE_ARGMAX) {  // logits processors (Suppress -> SuppressAtBegin) + running argmax, logits_process.py:1281-1311
                 v *= p.q_scale;
                 if (am_tr) am_tr[n] = v;
-                const uint8_t mk = p.am_mask[n];
+                const uint8_t mk = am_mk[cur];
                 if ((mk & 1) || ((mk & 2) && am_at_begin)) v = -INFINITY;
                 if (v > am_best || (v == am_best && n < am_bidx)) {
                     am_best = v;

@@ -246,6 +246,119 @@ __global__ __launch_bounds__(256, HBK_ == 64 ? 2 : 3) void gemm_f16_kernel(const
     }
 }
 
+// The same GEMM with both tiles staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), for K % 64 == 0
+// (every encoder GEMM but conv1).  128x128x64 tile, two 32 KiB stages, 2 blocks per CU.  One wave instruction writes 1 KiB
+// linearly = 8 rows x 128 B, so the LDS image is UNPADDED [row][8 chunks of 8 halfs] and the fragment reads are kept
+// conflict-free by an XOR swizzle applied on both sides (cdna guide §5.4 rule 21): LDS chunk position p of row r holds global
+// chunk p ^ ((r >> 1) & 7).  A 16-lane ds_read_b128 group (rows r..r+15, one logical chunk) then covers all 16 sixteen-byte
+// slots of the 256-byte bank row: rows 2a, 2a+1 share a swizzle and sit 128 B apart, the 8 values of a give 8 distinct positions.
+// Pipeline as in gemm_f32_dma_kernel: wait for tile kt, ONE barrier, first fragment reads, DMA of tile kt+1 into the other
+// stage (everyone is past its reads of that stage), 32 MFMAs.
+template <bool OUT_HALF>
+__global__ __launch_bounds__(256, 2) void gemm_f16_dma_kernel(const GemmParams p) {
+    constexpr int BK = 64;
+    __shared__ __attribute__((aligned(1024))) _Float16 smem[2][2][HBM_ * BK];  // [stage][A | W][row * 64 + pos * 8]
+    const __half* A = reinterpret_cast<const __half*>(p.A);
+    const __half* W = reinterpret_cast<const __half*>(p.W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * HBM_, n0 = bx * HBN_;
+
+    // DMA map: wave w, pass j fills rows j*32 + w*8 .. +7; lane -> (row lane >> 3, chunk position lane & 7)
+    const int r_local = lane >> 3;
+    const int csrc = (lane & 7) ^ (((wave * 8 + r_local) >> 1) & 7);   // (row >> 1) & 7 with row = j*32 + w*8 + r_local
+    const __half* aptr[4];
+    const __half* wptr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = j * 32 + wave * 8 + r_local;
+        const int m = min(m0 + row, p.M - 1);
+        const int bb = m / p.a_rows_per_batch;
+        aptr[j] = A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8;
+        wptr[j] = W + (long long)min(n0 + row, p.N - 1) * p.K + csrc * 8;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const int stage, const int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 32 + wave * 8) * BK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 32 + wave * 8) * BK]), 16, 0, 0);
+        }
+    };
+    // fragment reads (16x16x32: lane -> row l15 of the 16-row tile, 16-byte k-chunk kq + 4 s): tile i of A = rows wr*64 + 16 i + l15;
+    // (row >> 1) & 7 == (l15 >> 1) for every tile (16 i and wr*64 are multiples of 16)
+    const int swz = (l15 >> 1) & 7;
+    const int ra = (wr * 64 + l15) * BK, rb = (wc * 64 + l15) * BK;
+    const int po0 = ((kq + 0) ^ swz) * 8, po1 = ((kq + 4) ^ swz) * 8;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    dma(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
+        __syncthreads();                                   // ... everyone's has, and nobody still reads the other stage
+        const _Float16* As = &smem[cur][0][0];
+        const _Float16* Ws = &smem[cur][1][0];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int po = s ? po1 : po0;
+            h8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const h8*>(As + ra + i * 16 * BK + po);
+                bf[i] = *reinterpret_cast<const h8*>(Ws + rb + i * 16 * BK + po);
+            }
+            if (s == 0 && kt + 1 < nk) dma(cur ^ 1, kt + 1);  // after the first fragment reads are on their way
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: 16x16 C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        const int n = n0 + wc * 64 + tj * 16 + l15;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 64 + ti * 16 + kq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[ti][tj][r] + bv;
+                if (p.act) v = gelu_erf_h(v);
+                const int cb = m / p.c_rows_per_batch, cr = m - cb * p.c_rows_per_batch;
+                if (p.pos) v += p.pos[(long long)cr * p.N + n];
+                const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
+                if (p.resid) v += p.resid[off];
+                if (OUT_HALF) reinterpret_cast<__half*>(p.C)[off] = __float2half(v);
+                else p.C[off] = v;
+            }
+        }
+    }
+}
+
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
@@ -263,6 +376,12 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     }
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
     const dim3 grid(nbx * nby);
+    static const bool no_dma = getenv("WT_HGEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
+    if (!no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0) {
+        if (out_half) hipLaunchKernelGGL(gemm_f16_dma_kernel<true>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemm_f16_dma_kernel<false>, grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     if (bk == 64) {
         if (out_half) hipLaunchKernelGGL((gemm_f16_kernel<true, 64>), grid, dim3(256), hgemm_smem<64>(), s, p);
         else hipLaunchKernelGGL((gemm_f16_kernel<false, 64>), grid, dim3(256), hgemm_smem<64>(), s, p);
