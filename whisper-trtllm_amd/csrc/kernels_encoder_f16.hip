@@ -246,6 +246,85 @@ __global__ __launch_bounds__(256, HBK_ == 64 ? 2 : 3) void gemm_f16_kernel(const
     }
 }
 
+// Epilogue of the LDS-DMA kernel.  The 16x16 accumulator map gives a lane one column and four rows per tile: stored as it
+// stands, every store instruction writes 4-byte (fp32) or 2-byte (fp16) elements in 64- / 32-byte pieces, and the bias / residual /
+// position reads are gathers of the same shape -- measured, that epilogue was ~60 % of a K = 1024 launch.  Here each wave
+// transposes its 64x64 tile through its own 32 x 68-float LDS scratch (two halves of 32 rows; the stage buffers are free by
+// now), so that a lane owns FOUR CONSECUTIVE columns of one row: bias / residual / position rows are read as float4, the
+// output is written as 16-byte (fp32) or 8-byte (fp16) pieces, whole 256- / 128-byte rows per 16 lanes, and the batch split
+// (row -> utterance, row in utterance) is one wave-uniform division plus a carry per row instead of a division per element.
+constexpr int EPI_LD = 68;  // scratch row stride in floats: 16-byte aligned rows, kq = 1 rows land 16 banks away from kq = 0
+template <bool OUT_HALF>
+__device__ __forceinline__ void hgemm_epilogue_lds(const GemmParams& p, const f32x4 (&acc)[4][4], const int m0, const int n0, const int wr,
+                                                   const int wc, const int lane, float* __restrict__ ew) {
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n = n0 + wc * 64 + 4 * l15;               // first of this lane's four output columns
+    const bool vec = (n + 3 < p.N) && ((p.ldc & 3) == 0) && ((p.c_batch_stride & 3) == 0) && ((p.N & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(p.pos) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+        if (vec) bv = *reinterpret_cast<const float4*>(p.bias + n);
+        else {
+            bv.x = n < p.N ? p.bias[n] : 0.f; bv.y = n + 1 < p.N ? p.bias[n + 1] : 0.f;
+            bv.z = n + 2 < p.N ? p.bias[n + 2] : 0.f; bv.w = n + 3 < p.N ? p.bias[n + 3] : 0.f;
+        }
+    }
+    const int mw = m0 + wr * 64;                          // first row of this wave's tile (wave-uniform)
+    const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ew[(t2 * 16 + kq * 4 + r) * EPI_LD + tj * 16 + l15] = acc[2 * half + t2][tj][r];
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int lr = pass * 4 + kq;                 // row of this half handled by this lane
+            const float4 a = *reinterpret_cast<const float4*>(&ew[lr * EPI_LD + 4 * l15]);
+            const int o = half * 32 + lr;
+            if (mw + o >= p.M) continue;
+            int cb = cb_w, cr = cr_w + o;
+            while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
+            const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
+            float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+            if (p.act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_h(v[e]);
+            }
+            if (vec) {
+                if (p.pos) {
+                    const float4 q = *reinterpret_cast<const float4*>(p.pos + (long long)cr * p.N + n);
+                    v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+                }
+                if (p.resid) {
+                    const float4 q = *reinterpret_cast<const float4*>(p.resid + off);
+                    v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+                }
+                if (OUT_HALF) {
+                    __half2* dst = reinterpret_cast<__half2*>(reinterpret_cast<__half*>(p.C) + off);
+                    dst[0] = __floats2half2_rn(v[0], v[1]);
+                    dst[1] = __floats2half2_rn(v[2], v[3]);
+                } else {
+                    *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) continue;
+                    float x = v[e];
+                    if (p.pos) x += p.pos[(long long)cr * p.N + n + e];
+                    if (p.resid) x += p.resid[off + e];
+                    if (OUT_HALF) reinterpret_cast<__half*>(p.C)[off + e] = __float2half(x);
+                    else p.C[off + e] = x;
+                }
+            }
+        }
+    }
+}
+
 // The same GEMM with both tiles staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), for K % 64 == 0
 // (every encoder GEMM but conv1).  128x128x64 tile, two 32 KiB stages, 2 blocks per CU.  One wave instruction writes 1 KiB
 // linearly = 8 rows x 128 B, so the LDS image is UNPADDED [row][8 chunks of 8 halfs] and the fragment reads are kept
@@ -334,29 +413,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_dma_kernel(const GemmParams p
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    // epilogue: 16x16 C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-        const int n = n0 + wc * 64 + tj * 16 + l15;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + ti * 16 + kq * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[ti][tj][r] + bv;
-                if (p.act) v = gelu_erf_h(v);
-                const int cb = m / p.c_rows_per_batch, cr = m - cb * p.c_rows_per_batch;
-                if (p.pos) v += p.pos[(long long)cr * p.N + n];
-                const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
-                if (p.resid) v += p.resid[off];
-                if (OUT_HALF) reinterpret_cast<__half*>(p.C)[off] = __float2half(v);
-                else p.C[off] = v;
-            }
-        }
-    }
+    __syncthreads();  // every wave is past its last fragment read: the stage buffers become the epilogue scratch
+    hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(&smem[0][0][0]) + wave * (32 * EPI_LD));
 }
 
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
