@@ -417,6 +417,104 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_dma_kernel(const GemmParams p
     hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(&smem[0][0][0]) + wave * (32 * EPI_LD));
 }
 
+// 256x128x64 tile, 8 waves (4 x 2, 64x64 per wave), THREE 48 KiB stages, one block per CU: two tiles of LDS-DMA stay in flight
+// across the barrier.  Why: the 128x128 kernel above is bound by L2 -> LDS latency, not by MFMA issue -- per K-tile it needs 32 KiB
+// per block and has one tile (2 blocks x 32 KiB per CU) in flight, ~1.1 us per K-tile against 0.43 us of MFMA time.  This shape
+// needs 25 % fewer operand bytes per flop and keeps 96 KiB in flight per CU.  Synchronisation per K-tile: a COUNTED
+// `s_waitcnt vmcnt(6)` (this wave's six DMA instructions of the NEWEST tile may stay outstanding; everything older has landed),
+// then a raw `s_barrier` -- never __syncthreads(), whose fence waits vmcnt(0) and would drain the tile in flight (cdna guide §5,
+// "Pipelining across barriers").  The barrier at the top of iteration kt orders (a) every wave's share of tile kt landed -> reads
+// of stage kt % 3, and (b) every wave done with its reads of stage (kt - 1) % 3 -> the DMA of tile kt + 2 into that stage.
+constexpr int H3_BM = 256, H3_BN = 128, H3_BK = 64, H3_STAGE = (H3_BM + H3_BN) * H3_BK;   // halfs per stage (48 KiB)
+constexpr int H3_SMEM = 3 * H3_STAGE * 2;                                                  // 147,456 B
+template <bool OUT_HALF>
+__global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char h3_raw[];
+    _Float16* smem = reinterpret_cast<_Float16*>(h3_raw);   // [stage][A 256 rows | W 128 rows][row * 64 + pos * 8]
+    const __half* A = reinterpret_cast<const __half*>(p.A);
+    const __half* W = reinterpret_cast<const __half*>(p.W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;                 // 4 x 2 waves, 64 x 64 each
+
+    const int nbx = (p.N + H3_BN - 1) / H3_BN, nby = (p.M + H3_BM - 1) / H3_BM, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * H3_BM, n0 = bx * H3_BN;
+
+    // DMA map: one wave instruction = 8 rows x 128 B.  A: 32 instructions (wave w, pass j < 4: rows j*64 + w*8 ..),
+    // W: 16 instructions (pass j < 2).  lane -> (row lane >> 3, chunk position lane & 7); source chunk = pos ^ ((row >> 1) & 7)
+    const int r_local = lane >> 3;
+    const int csrc = (lane & 7) ^ (((wave * 8 + r_local) >> 1) & 7);
+    const __half* aptr[4];
+    const __half* wptr[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = min(m0 + j * 64 + wave * 8 + r_local, p.M - 1);
+        const int bb = m / p.a_rows_per_batch;
+        aptr[j] = A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wptr[j] = W + (long long)min(n0 + j * 64 + wave * 8 + r_local, p.N - 1) * p.K + csrc * 8;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const int stage, const int kt) {
+        _Float16* st = smem + stage * H3_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * H3_BK), (lptr_t)(st + (j * 64 + wave * 8) * H3_BK), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * H3_BK), (lptr_t)(st + H3_BM * H3_BK + (j * 64 + wave * 8) * H3_BK), 16, 0, 0);
+    };
+    const int swz = (l15 >> 1) & 7;
+    const int ra = (wr * 64 + l15) * H3_BK, rb = H3_BM * H3_BK + (wc * 64 + l15) * H3_BK;
+    const int po0 = ((kq + 0) ^ swz) * 8, po1 = ((kq + 4) ^ swz) * 8;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / H3_BK;
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt has landed (tile kt+1: 6 instructions may fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) dma(cur == 0 ? 2 : cur - 1, kt + 2);               // stage (kt + 2) % 3 == (kt - 1) % 3: free since the barrier
+        const _Float16* st = smem + cur * H3_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int po = s2 ? po1 : po0;
+            h8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const h8*>(st + ra + i * 16 * H3_BK + po);
+                bf[i] = *reinterpret_cast<const h8*>(st + rb + i * 16 * H3_BK + po);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();  // every wave is past its last fragment read (and no DMA is outstanding): the stages become the epilogue scratch
+    hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(h3_raw) + wave * (32 * EPI_LD));
+}
+
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
@@ -435,7 +533,22 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
     const dim3 grid(nbx * nby);
     static const bool no_dma = getenv("WT_HGEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
-    if (!no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0) {
+    static const int variant = getenv("WT_HGEMM_VARIANT") ? atoi(getenv("WT_HGEMM_VARIANT")) : 3;  // 2: 128x128 two-stage, 3: 256x128 three-stage
+    const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
+    if (dma_ok && variant == 3 && p.M >= 1024) {   // small problems: the 128x128 tiles fill the chip better
+        static PerDeviceFlag attr3;
+        if (!attr3.get()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_SMEM);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_SMEM);
+            if (e != hipSuccess) return e;
+            attr3.set();
+        }
+        const dim3 grid3(((p.N + H3_BN - 1) / H3_BN) * ((p.M + H3_BM - 1) / H3_BM));
+        if (out_half) hipLaunchKernelGGL(gemm_f16_dma3_kernel<true>, grid3, dim3(512), H3_SMEM, s, p);
+        else hipLaunchKernelGGL(gemm_f16_dma3_kernel<false>, grid3, dim3(512), H3_SMEM, s, p);
+        return hipGetLastError();
+    }
+    if (dma_ok) {
         if (out_half) hipLaunchKernelGGL(gemm_f16_dma_kernel<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(gemm_f16_dma_kernel<false>, grid, dim3(256), 0, s, p);
         return hipGetLastError();
