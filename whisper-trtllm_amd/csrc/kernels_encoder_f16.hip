@@ -533,9 +533,14 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
     const dim3 grid(nbx * nby);
     static const bool no_dma = getenv("WT_HGEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
-    static const int variant = getenv("WT_HGEMM_VARIANT") ? atoi(getenv("WT_HGEMM_VARIANT")) : 3;  // 2: 128x128 two-stage, 3: 256x128 three-stage
+    // A/B override: WT_HGEMM_VARIANT=2 forces the 128x128 two-stage kernel, 3 the 256x128 three-stage kernel wherever M >= 1024.
+    // Default (measured, TFLOP/s, two-stage vs three-stage): M = 12000: K 1024 688 vs 623 (N 3072), 588 vs 517 (N 1024), 604 vs 550
+    // (N 4096, GELU, fp16 out); K 4096 805 vs 714.  M = 24000: K 1024 687 vs 675, 678 vs 675, 622 vs 611; K 4096 823 vs 876,
+    // K 3072 773 vs 811.  So: three-stage for the long-K GEMMs of big batches (fc2 and conv2 at batch 16), two-stage otherwise.
+    static const int variant = getenv("WT_HGEMM_VARIANT") ? atoi(getenv("WT_HGEMM_VARIANT")) : 0;
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
-    if (dma_ok && variant == 3 && p.M >= 1024) {   // small problems: the 128x128 tiles fill the chip better
+    const bool use3 = variant == 3 ? p.M >= 1024 : variant == 2 ? false : (p.M >= 16384 && p.K >= 2048);
+    if (dma_ok && use3) {
         static PerDeviceFlag attr3;
         if (!attr3.get()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_SMEM);
