@@ -18,6 +18,9 @@ int wt_dbg_gemm(const float* A, int lda, const float* W, const float* bias, cons
 /* fp16 operands (A [M][K(lda)], W [N][K] as IEEE half), fp32 accumulate; C is half when out_half else float */
 int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N, int K,
                     int act, int out_half, void* stream);
+/* the same with the LDS-DMA kernel forced (K % 64 == 0): variant 2 = 128x128 two-stage, 3 = 256x128 three-stage; 0 = by shape */
+int wt_dbg_gemm_f16_variant(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N, int K,
+                            int act, int out_half, int variant, void* stream);
 int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream);
 /* qkv [B*S][3*H*64] -> ctx [B*S][H*64], softmax(QK^T/8)V per head */
 int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, void* stream);

@@ -74,6 +74,33 @@ def test_gemm_f16(lib, M, N, K, act, out_half, use_res):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
+    (130, 70, 64, 0, 0, False), (257, 129, 128, 1, 1, False), (1500, 1024, 4096, 0, 0, True), (3000, 1024, 3072, 1, 0, False),
+    (1024, 3072, 1024, 0, 1, False), (300, 200, 192, 0, 0, True), (256, 128, 64, 0, 0, False), (511, 383, 640, 1, 1, False)])
+def test_gemm_f16_lds_dma_kernels(lib, variant, M, N, K, act, out_half, use_res):
+    """Both LDS-DMA fp16 GEMM kernels (128x128 two-stage; 256x128 three-stage with counted vmcnt + raw barrier) forced at sizes the
+    shape rule would not give them: ragged M / N tiles, 1..64 K-tiles, every epilogue form."""
+    A, W, b = _rand(M, K, seed=1).half(), _rand(N, K, seed=2, scale=K ** -0.5).half(), _rand(N, seed=3)
+    R = _rand(M, N, seed=4) if use_res else None
+    ref = F.linear(A.double(), W.double(), b.double())
+    if act:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    C = (R.cuda().clone() if use_res else torch.empty(M, N, device="cuda"))
+    if out_half:
+        C = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    for _ in range(2):
+        C0 = R.cuda().clone() if use_res else C
+        assert lib.wt_dbg_gemm_f16_variant(P(Ad), K, P(Wd), P(bd), P(C0) if use_res else None, P(C0), M, N, K, act, out_half, variant, _stream()) == 0
+    torch.cuda.synchronize()
+    err = (C0.cpu().double() - ref).abs().max().item()
+    tol = (2e-3 if out_half else 2e-5) * max(1.0, ref.abs().max().item())
+    assert err < tol, err
+
+
 @pytest.mark.parametrize("n", [160, 192, 256])   # 192, 256: K % 64 == 0 -> the LDS-DMA kernel (swizzled unpadded tiles)
 def test_gemm_f16_identity_asymmetric(lib, n):
     A = torch.eye(n).half()

@@ -86,6 +86,15 @@ extern "C" int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const floa
     return rc_of(launch_gemm_f16(g, out_half != 0, (hipStream_t)stream));
 }
 
+extern "C" int wt_dbg_gemm_f16_variant(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N,
+                                       int K, int act, int out_half, int variant, void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = (const float*)A; g.lda = lda; g.a_rows_per_batch = M; g.W = (const float*)W; g.bias = bias; g.resid = resid;
+    g.C = (float*)C; g.ldc = N; g.c_rows_per_batch = M; g.M = M; g.N = N; g.K = K; g.act = act;
+    return rc_of(launch_gemm_f16(g, out_half != 0, (hipStream_t)stream, variant));
+}
+
 extern "C" int wt_dbg_encoder_attention_f16(const void* qkv, void* ctx, int B, int S, int H, void* stream) {
     return rc_of(launch_encoder_attention_f16(qkv, ctx, B, S, H, (hipStream_t)stream));
 }

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
     hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(h3_raw) + wave * (32 * EPI_LD));
 }
 
-hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
+hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
     static PerDeviceFlag attr_set;
@@ -537,9 +537,10 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s) {
     // Default (measured, TFLOP/s, two-stage vs three-stage): M = 12000: K 1024 688 vs 623 (N 3072), 588 vs 517 (N 1024), 604 vs 550
     // (N 4096, GELU, fp16 out); K 4096 805 vs 714.  M = 24000: K 1024 687 vs 675, 678 vs 675, 622 vs 611; K 4096 823 vs 876,
     // K 3072 773 vs 811.  So: three-stage for the long-K GEMMs of big batches (fc2 and conv2 at batch 16), two-stage otherwise.
-    static const int variant = getenv("WT_HGEMM_VARIANT") ? atoi(getenv("WT_HGEMM_VARIANT")) : 0;
+    static const int env_variant = getenv("WT_HGEMM_VARIANT") ? atoi(getenv("WT_HGEMM_VARIANT")) : 0;
+    const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach both kernels at small sizes
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
-    const bool use3 = variant == 3 ? p.M >= 1024 : variant == 2 ? false : (p.M >= 16384 && p.K >= 2048);
+    const bool use3 = variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 ? false : (p.M >= 16384 && p.K >= 2048);
     if (dma_ok && use3) {
         static PerDeviceFlag attr3;
         if (!attr3.get()) {

@@ -127,7 +127,7 @@ hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, 
 hipError_t launch_mel_transpose_h(const float* mel, void* melT, int B, int n_mels, int frames, hipStream_t s);
 hipError_t launch_layernorm_h(const float* x, const float* w, const float* b, void* y, int rows, int d, hipStream_t s);
 hipError_t launch_cast_h(const float* x, void* y, size_t n, hipStream_t s);
-hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s);
+hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant = 0);  // 0: by shape; 2 / 3: see kernels_encoder_f16.hip
 hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S, int H, hipStream_t s);  // half in, half out  // p.A / p.W point at __half data
 
 hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
