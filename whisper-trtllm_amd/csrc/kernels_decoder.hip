@@ -774,24 +774,31 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
 __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p) {
     __shared__ int s_tok[16];
     __shared__ int s_pos;
-    __shared__ float s_wv[4];
-    __shared__ int s_wi[4];
+    __shared__ int s_unf[16];
     DecState* st = p.st;
     if (st->done) return;
     const int tid = threadIdx.x, cur_len = st->cur_len, step = st->step;
-    for (int b = 0; b < p.B; ++b) {  // final masked argmax of row b over the n_parts partial results (lowest index on ties)
+    // final masked argmax of every row over its n_parts partial results (lowest index on ties).  All rows at once: a group of
+    // `lpb` lanes per row (32 at B <= 8, 16 at B <= 16), every load of the block in flight together -- the partials were written by
+    // other XCDs a kernel ago, so this is one memory round trip; row by row it was B of them (measured 14 us per step at B = 8).
+    {
+        const int lpb = p.B <= 4 ? 64 : p.B <= 8 ? 32 : 16;
+        const int b = tid / lpb, l = tid % lpb;
         float best = -INFINITY;
         int bidx = 0x7fffffff;
-        for (int i = tid; i < p.n_parts; i += 256) {
-            const float v = p.part_val[(size_t)b * p.n_parts + i];
-            const int ix = p.part_idx[(size_t)b * p.n_parts + i];
-            if (v > best || (v == best && ix < bidx)) {
-                best = v;
-                bidx = ix;
+        const int forced = p.forced[cur_len];                          // ForceTokensLogitsProcessor (requested with the partials)
+        const int unf = p.unfinished[min(b, p.B - 1)];
+        if (b < p.B) {
+            for (int i = l; i < p.n_parts; i += lpb) {
+                const float v = p.part_val[(size_t)b * p.n_parts + i];
+                const int ix = p.part_idx[(size_t)b * p.n_parts + i];
+                if (v > best || (v == best && ix < bidx)) {
+                    best = v;
+                    bidx = ix;
+                }
             }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
+        for (int o = lpb >> 1; o >= 1; o >>= 1) {   // lpb <= 64 and a power of two: a group never straddles a wave
             const float ov = __shfl_xor(best, o);
             const int oi = __shfl_xor(bidx, o);
             if (ov > best || (ov == best && oi < bidx)) {
@@ -799,31 +806,21 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
                 bidx = oi;
             }
         }
-        if ((tid & 63) == 0) {
-            s_wv[tid >> 6] = best;
-            s_wi[tid >> 6] = bidx;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < 4; ++i)
-                if (s_wv[i] > best || (s_wv[i] == best && s_wi[i] < bidx)) {
-                    best = s_wv[i];
-                    bidx = s_wi[i];
-                }
+        if (b < p.B && l == 0) {
             int tok = bidx;
-            const int forced = p.forced[cur_len];                 // ForceTokensLogitsProcessor
             if (forced >= 0) tok = forced;
             if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
-            if (!p.unfinished[b]) tok = p.pad;                     // finished rows keep emitting pad
+            if (!unf) tok = p.pad;                                 // finished rows keep emitting pad
             p.ids[(size_t)b * p.max_length + cur_len] = tok;
             if (tok == p.eos) p.unfinished[b] = 0;
             s_tok[b] = tok;
+            s_unf[b] = (tok == p.eos) ? 0 : unf;
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
         int nu = 0;
-        for (int b = 0; b < p.B; ++b) nu += p.unfinished[b] ? 1 : 0;
+        for (int b = 0; b < p.B; ++b) nu += s_unf[b] ? 1 : 0;
         st->n_unfinished = nu;
         st->cur_len = cur_len + 1;
         st->pos += 1;
