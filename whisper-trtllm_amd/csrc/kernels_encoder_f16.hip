@@ -484,32 +484,62 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Two-phase software pipeline over the two 32-deep k-steps of a tile (p0, p1), fragments double-buffered in registers:
+    //   reads(kt, p1) | MFMA(kt, p0) | wait tile kt+1 + barrier | DMA(kt+3 -> stage kt%3) | reads(kt+1, p0) | MFMA(kt, p1)
+    // so every batch of 16 MFMAs runs under the LDS reads of the NEXT batch, and the counted wait + barrier are reached with 16
+    // MFMAs already queued.  Three tiles are in flight at the top of the loop, two across the barrier.
+    //   RAW: a wave reads stage (kt+1)%3 only after its own vmcnt wait for tile kt+1 AND the barrier behind it.
+    //   WAR: DMA(kt+3) overwrites stage kt%3 after the barrier that every wave reaches with its reads of (kt, p1) retired (lgkmcnt(0)).
     const int nk = p.K / H3_BK;
     dma(0, 0);
     if (nk > 1) dma(1, 1);
+    if (nk > 2) dma(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    h8 fa0[4], fb0[4], fa1[4], fb1[4];
+    auto frag = [&](h8 (&fa)[4], h8 (&fb)[4], const int stage, const int po) {
+        const _Float16* st = smem + stage * H3_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = *reinterpret_cast<const h8*>(st + ra + i * 16 * H3_BK + po);
+            fb[i] = *reinterpret_cast<const h8*>(st + rb + i * 16 * H3_BK + po);
+        }
+    };
+    auto mma = [&](const h8 (&fa)[4], const h8 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    frag(fa0, fb0, 0, po0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): both edges into the loop header carry an empty LDS scoreboard (see the loop's end)
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt has landed (tile kt+1: 6 instructions may fly)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nk) dma(cur == 0 ? 2 : cur - 1, kt + 2);               // stage (kt + 2) % 3 == (kt - 1) % 3: free since the barrier
-        const _Float16* st = smem + cur * H3_STAGE;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int po = s2 ? po1 : po0;
-            h8 af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const h8*>(st + ra + i * 16 * H3_BK + po);
-                bf[i] = *reinterpret_cast<const h8*>(st + rb + i * 16 * H3_BK + po);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        frag(fa1, fb1, cur, po1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my reads of stage `cur` are done (16 MFMAs were queued behind them)
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 landed (tile kt+2 may fly)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 3 < nk) dma(cur, kt + 3);
+            frag(fa0, fb0, nxt, po0);
         }
-        cur = cur == 2 ? 0 : cur + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // The reads of (kt+1, p0) have had 16 MFMAs to land.  Retire them HERE with the builtin (which hipcc's waitcnt pass tracks;
+        // an asm wait it does not): otherwise the pass, unsure what is pending across the back edge, puts `lgkmcnt(0)` in front of
+        // the next iteration's MFMA(kt+1, p0) -- behind the reads of (kt+1, p1) it was supposed to overlap.
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) alone
+        cur = nxt;
     }
     __syncthreads();  // every wave is past its last fragment read (and no DMA is outstanding): the stages become the epilogue scratch
     hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(h3_raw) + wave * (32 * EPI_LD));
