@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_pair_kernel(c
 }
 
 template <int NB, int V, int NW>
-static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
+static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out, int tg_override = 0) {
     if (p.B < 1 || p.B > NB || (p.K & 3)) return hipErrorInvalidValue;
     int nsplit = 1;
     while (p.K / nsplit > 256 * V || (p.K % nsplit)) {
@@ -439,7 +439,7 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out) {
     // (only the 8-row template: batch 16 measured 424 audio-s/s with 2048 and 398 with 1024; batch 1 / 2 / 4: 1.07 / 1.11 / 1.24 ms
     //  per step with 2048 and 1.09 / 1.12 / 1.27 with 1024; batch 6: 1.44 vs 1.41)
     static const int tg_total = getenv("WT_SKINNY_TARGET") ? atoi(getenv("WT_SKINNY_TARGET")) : (NB == 8 ? 1024 : 2048);
-    const int target_groups = tg_total / nsplit;
+    const int target_groups = (tg_override > 0 ? tg_override : tg_total) / nsplit;
     int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
     if (rows_per_group < 2) rows_per_group = 2;
     const int groups = (p.N + rows_per_group - 1) / rows_per_group;
@@ -480,6 +480,14 @@ static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, 
     SkinnyPlan pa, pb;
     hipError_t e = skinny_plan<NB, V, NW>(a, &pa);
     if (e == hipSuccess) e = skinny_plan<NB, V, NW>(b, &pb);
+    // 8-wave workgroups (batch 9..16) are resident one per CU: a pair of more than 256 of them runs in two rounds, the second
+    // half empty (measured 12.5 us per launch at medium.en batch 16 with 128 + 256 workgroups).  Re-plan both halves with fewer,
+    // fatter row groups until the pair fits one round.
+    if (NW == 8)
+        for (int tg = 1024; e == hipSuccess && pa.grid + pb.grid > 256 && tg >= 256; tg >>= 1) {
+            e = skinny_plan<NB, V, NW>(a, &pa, tg);
+            if (e == hipSuccess) e = skinny_plan<NB, V, NW>(b, &pb, tg);
+        }
     if (e == hipSuccess) e = skinny_smem_attr<NB, V, NW>();
     if (e != hipSuccess) return e;
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
