@@ -417,37 +417,140 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_dma_kernel(const GemmParams p
     hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(&smem[0][0][0]) + wave * (32 * EPI_LD));
 }
 
-// 256x128x64 tile, 8 waves (4 x 2, 64x64 per wave), THREE 48 KiB stages, one block per CU: two tiles of LDS-DMA stay in flight
-// across the barrier.  Why: the 128x128 kernel above is bound by L2 -> LDS latency, not by MFMA issue -- per K-tile it needs 32 KiB
-// per block and has one tile (2 blocks x 32 KiB per CU) in flight, ~1.1 us per K-tile against 0.43 us of MFMA time.  This shape
-// needs 25 % fewer operand bytes per flop and keeps 96 KiB in flight per CU.  Synchronisation per K-tile: a COUNTED
-// `s_waitcnt vmcnt(6)` (this wave's six DMA instructions of the NEWEST tile may stay outstanding; everything older has landed),
-// then a raw `s_barrier` -- never __syncthreads(), whose fence waits vmcnt(0) and would drain the tile in flight (cdna guide §5,
-// "Pipelining across barriers").  The barrier at the top of iteration kt orders (a) every wave's share of tile kt landed -> reads
-// of stage kt % 3, and (b) every wave done with its reads of stage (kt - 1) % 3 -> the DMA of tile kt + 2 into that stage.
+// Epilogue of the persistent kernel below: the same transposition through LDS, in EIGHT passes of 8 rows per wave (2 KiB of
+// scratch per wave -- all that is left beside three 48 KiB stages in 160 KiB).  Pass (ti, rb): the 8 rows kq*4 + rb + {0, 1} of
+// accumulator row-tile ti.  Scratch image [8 rows][64 floats], unpadded; XOR swizzle on the column, (row >> 1 & 1) << 4 ^ (row & 1) << 2:
+// the two kq values of a 32-lane ds_write_b32 group land in different 16-bank groups, and the two rows of a 16-lane ds_read_b128
+// group in alternating 16-byte slots.  A lane then owns columns 4c..4c+3 and 32+4c..32+4c+3 of one row.
+template <bool OUT_HALF>
+__device__ __forceinline__ void hgemm_epilogue_lds8(const GemmParams& p, const f32x4 (&acc)[4][4], const int m0, const int n0, const int wr,
+                                                    const int wc, const int lane, float* __restrict__ ew) {
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int lr = lane >> 3, c = lane & 7;                   // read side: row of the pass, column chunk
+    const int rswz = (((lr >> 1) & 1) << 4) ^ ((lr & 1) << 2);
+    const int nn[2] = {n0 + wc * 64 + 4 * c, n0 + wc * 64 + 32 + 4 * c};
+    const bool aligned = ((p.ldc & 3) == 0) && ((p.c_batch_stride & 3) == 0) && ((p.N & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.pos) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    bool vec[2];
+    float4 bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        vec[h] = aligned && (nn[h] + 3 < p.N);
+        bv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            if (vec[h]) bv[h] = *reinterpret_cast<const float4*>(p.bias + nn[h]);
+            else {
+                bv[h].x = nn[h] < p.N ? p.bias[nn[h]] : 0.f; bv[h].y = nn[h] + 1 < p.N ? p.bias[nn[h] + 1] : 0.f;
+                bv[h].z = nn[h] + 2 < p.N ? p.bias[nn[h] + 2] : 0.f; bv[h].w = nn[h] + 3 < p.N ? p.bias[nn[h] + 3] : 0.f;
+            }
+        }
+    }
+    // Pin a USE of the bias registers here: every row of an M-edge tile may `continue` below, and a load whose result is only used on
+    // some paths is still pending, as far as hipcc's waitcnt pass can tell, at the K-loop's back edge -- it then drains vmcnt(0)
+    // (= every LDS-DMA in flight) at the top of EVERY K-step before it reuses those registers.
+    asm volatile("" ::"v"(bv[0].x), "v"(bv[0].y), "v"(bv[0].z), "v"(bv[0].w), "v"(bv[1].x), "v"(bv[1].y), "v"(bv[1].z), "v"(bv[1].w));
+    const int mw = m0 + wr * 64;
+    const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb += 2) {
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    ew[(kq * 2 + rr) * 64 + ((tj * 16 + l15) ^ ((kq & 1) << 4) ^ (rr << 2))] = acc[ti][tj][rb + rr];
+            float4 a[2];
+            a[0] = *reinterpret_cast<const float4*>(&ew[lr * 64 + ((4 * c) ^ rswz)]);
+            a[1] = *reinterpret_cast<const float4*>(&ew[lr * 64 + ((32 + 4 * c) ^ rswz)]);
+            const int o = ti * 16 + (lr >> 1) * 4 + rb + (lr & 1);   // row of the wave tile this lane finishes in this pass
+            if (mw + o >= p.M) continue;
+            int cb = cb_w, cr = cr_w + o;
+            while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
+            const long long rowoff = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long long off = rowoff + nn[h];
+                float v[4] = {a[h].x + bv[h].x, a[h].y + bv[h].y, a[h].z + bv[h].z, a[h].w + bv[h].w};
+                if (p.act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_h(v[e]);
+                }
+                if (vec[h]) {
+                    if (p.pos) {
+                        const float4 q = *reinterpret_cast<const float4*>(p.pos + (long long)cr * p.N + nn[h]);
+                        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+                    }
+                    if (p.resid) {
+                        const float4 q = *reinterpret_cast<const float4*>(p.resid + off);
+                        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+                    }
+                    if (OUT_HALF) {
+                        __half2* dst = reinterpret_cast<__half2*>(reinterpret_cast<__half*>(p.C) + off);
+                        dst[0] = __floats2half2_rn(v[0], v[1]);
+                        dst[1] = __floats2half2_rn(v[2], v[3]);
+                    } else {
+                        *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (nn[h] + e >= p.N) continue;
+                        float x = v[e];
+                        if (p.pos) x += p.pos[(long long)cr * p.N + nn[h] + e];
+                        if (p.resid) x += p.resid[off + e];
+                        if (OUT_HALF) reinterpret_cast<__half*>(p.C)[off + e] = __float2half(x);
+                        else p.C[off + e] = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// PERSISTENT 256x128x64 kernel for the big-batch GEMMs: 8 waves (4 x 2, 64x64 per wave), THREE 48 KiB stages + 16 KiB of epilogue
+// scratch = the whole 160 KiB LDS, one workgroup per CU looping over its tiles (t = blockIdx, blockIdx + grid, ...: a block keeps
+// its XCD label, so the XCD-chunked tile order survives).
+// Why this shape: the 128x128 kernel above is bound by L2 -> LDS latency, not by MFMA issue -- per K-tile it needs 32 KiB per block and
+// has one tile (2 blocks x 32 KiB per CU) in flight, ~1.1 us per K-tile against 0.43 us of MFMA time.  This one needs 25 % fewer
+// operand bytes per flop and keeps 96 KiB in flight per CU; and as ONE stream of K-steps over all its tiles its LDS-DMA pipeline never
+// drains: the first K-tiles of tile T+1 are requested while tile T is still multiplying and land under T's epilogue (a one-tile
+// kernel at one block per CU exposes ~2 us of first-tile latency plus the epilogue per tile: a third of a K = 1024 tile).
+// Synchronisation per K-step: a COUNTED `s_waitcnt vmcnt(6)` (this wave's six DMA instructions of the NEWEST step may stay
+// outstanding; everything older has landed), then a raw `s_barrier` -- never __syncthreads(), whose fence waits vmcnt(0) and would
+// drain the step in flight (cdna guide §5, "Pipelining across barriers").  The barrier inside step g orders (a) every wave's share
+// of step g+1 landed -> reads of stage (g+1) % 3, and (b) every wave done with its reads of stage g % 3 -> the DMA of step g+3 into it.
+// Epilogue stores / residual loads are younger vector-memory operations than the DMAs in flight, so the counted wait after an
+// epilogue only over-waits (vmcnt retires in order), never under-waits.
 constexpr int H3_BM = 256, H3_BN = 128, H3_BK = 64, H3_STAGE = (H3_BM + H3_BN) * H3_BK;   // halfs per stage (48 KiB)
-constexpr int H3_SMEM = 3 * H3_STAGE * 2;                                                  // 147,456 B
+constexpr int H3_SCRATCH = 8 * 8 * 64 * 4;                                                 // 8 waves x [8 rows][64 floats]
+constexpr int H3_SMEM = 3 * H3_STAGE * 2 + H3_SCRATCH;                                     // 163,840 B = 160 KiB
 template <bool OUT_HALF>
 __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char h3_raw[];
-    _Float16* smem = reinterpret_cast<_Float16*>(h3_raw);   // [stage][A 256 rows | W 128 rows][row * 64 + pos * 8]
+    _Float16* smem = reinterpret_cast<_Float16*>(h3_raw);   // [stage][A 256 rows | W 128 rows][row * 64 + pos * 8], then the scratch
     const __half* A = reinterpret_cast<const __half*>(p.A);
     const __half* W = reinterpret_cast<const __half*>(p.W);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;                 // 4 x 2 waves, 64 x 64 each
+    float* ew = reinterpret_cast<float*>(h3_raw + 3 * H3_STAGE * 2) + wave * (8 * 64);
 
     const int nbx = (p.N + H3_BN - 1) / H3_BN, nby = (p.M + H3_BM - 1) / H3_BM, total = nbx * nby;
-    int bid = blockIdx.x;
-    {
+    const int G = gridDim.x;                                   // multiple of 8 or == total
+    const int ntiles = ((int)blockIdx.x < total) ? (total - (int)blockIdx.x + G - 1) / G : 0;
+    if (ntiles == 0) return;                                   // block-uniform
+    auto tile_origin = [&](const int i, int& m0, int& n0) {    // i-th tile of this workgroup
+        int bid = (int)blockIdx.x + i * G;
         const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * nbx, g = bid / per_group;
-    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
-    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
-    const int m0 = by * H3_BM, n0 = bx * H3_BN;
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * nbx, g = bid / per_group;
+        const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+        m0 = (g * GROUP_M + in_g % gm) * H3_BM;
+        n0 = (in_g / gm) * H3_BN;
+    };
 
     // DMA map: one wave instruction = 8 rows x 128 B.  A: 32 instructions (wave w, pass j < 4: rows j*64 + w*8 ..),
     // W: 16 instructions (pass j < 2).  lane -> (row lane >> 3, chunk position lane & 7); source chunk = pos ^ ((row >> 1) & 7)
@@ -455,14 +558,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
     const int csrc = (lane & 7) ^ (((wave * 8 + r_local) >> 1) & 7);
     const __half* aptr[4];
     const __half* wptr[2];
+    auto set_tile_ptrs = [&](const int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = min(m0 + j * 64 + wave * 8 + r_local, p.M - 1);
-        const int bb = m / p.a_rows_per_batch;
-        aptr[j] = A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8;
-    }
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(m0 + j * 64 + wave * 8 + r_local, p.M - 1);
+            const int bb = m / p.a_rows_per_batch;
+            aptr[j] = A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8;
+        }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wptr[j] = W + (long long)min(n0 + j * 64 + wave * 8 + r_local, p.N - 1) * p.K + csrc * 8;
+        for (int j = 0; j < 2; ++j) wptr[j] = W + (long long)min(n0 + j * 64 + wave * 8 + r_local, p.N - 1) * p.K + csrc * 8;
+    };
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto dma = [&](const int stage, const int kt) {
@@ -484,18 +591,26 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Two-phase software pipeline over the two 32-deep k-steps of a tile (p0, p1), fragments double-buffered in registers:
-    //   reads(kt, p1) | MFMA(kt, p0) | wait tile kt+1 + barrier | DMA(kt+3 -> stage kt%3) | reads(kt+1, p0) | MFMA(kt, p1)
+    // Two-phase software pipeline over the two 32-deep k-steps (p0, p1) of a K-step, fragments double-buffered in registers:
+    //   reads(g, p1) | MFMA(g, p0) | wait step g+1 + barrier | DMA(step g+3 -> stage g%3) | reads(g+1, p0) | MFMA(g, p1)
     // so every batch of 16 MFMAs runs under the LDS reads of the NEXT batch, and the counted wait + barrier are reached with 16
-    // MFMAs already queued.  Three tiles are in flight at the top of the loop, two across the barrier.
-    //   RAW: a wave reads stage (kt+1)%3 only after its own vmcnt wait for tile kt+1 AND the barrier behind it.
-    //   WAR: DMA(kt+3) overwrites stage kt%3 after the barrier that every wave reaches with its reads of (kt, p1) retired (lgkmcnt(0)).
+    // MFMAs already queued.  g runs over ALL K-steps of all tiles of this workgroup; the DMA cursor (d_i, d_kt) runs three steps ahead.
     const int nk = p.K / H3_BK;
-    dma(0, 0);
-    if (nk > 1) dma(1, 1);
-    if (nk > 2) dma(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    const int steps = ntiles * nk;
+    int d_i = 0, d_kt = 0;
+    set_tile_ptrs(0);
+    auto dma_next = [&](const int stage) {
+        dma(stage, d_kt);
+        if (++d_kt == nk) {
+            d_kt = 0;
+            if (++d_i < ntiles) set_tile_ptrs(d_i);
+        }
+    };
+    dma_next(0);
+    if (steps > 1) dma_next(1);
+    if (steps > 2) dma_next(2);
+    if (steps > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (steps > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -516,33 +631,41 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
     };
     frag(fa0, fb0, 0, po0);
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): both edges into the loop header carry an empty LDS scoreboard (see the loop's end)
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    int cur = 0, kt = 0, c_i = 0, m0, n0;
+    tile_origin(0, m0, n0);
+    for (int g = 0; g < steps; ++g) {
         const int nxt = cur == 2 ? 0 : cur + 1;
         frag(fa1, fb1, cur, po1);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my reads of stage `cur` are done (16 MFMAs were queued behind them)
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 landed (tile kt+2 may fly)
+        if (g + 1 < steps) {
+            if (g + 2 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step g+1 landed (step g+2 may fly)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 3 < nk) dma(cur, kt + 3);
+            if (g + 3 < steps) dma_next(cur);
             frag(fa0, fb0, nxt, po0);
         }
         __builtin_amdgcn_sched_barrier(0);
         mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        // The reads of (kt+1, p0) have had 16 MFMAs to land.  Retire them HERE with the builtin (which hipcc's waitcnt pass tracks;
+        // The reads of (g+1, p0) have had 16 MFMAs to land.  Retire them HERE with the builtin (which hipcc's waitcnt pass tracks;
         // an asm wait it does not): otherwise the pass, unsure what is pending across the back edge, puts `lgkmcnt(0)` in front of
-        // the next iteration's MFMA(kt+1, p0) -- behind the reads of (kt+1, p1) it was supposed to overlap.
+        // the next iteration's MFMA(g+1, p0) -- behind the reads of (g+1, p1) it was supposed to overlap.
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) alone
         cur = nxt;
+        if (++kt == nk) {   // this tile's K is complete: finish it under the flight of the next tile's first K-steps
+            hgemm_epilogue_lds8<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, ew);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            if (++c_i < ntiles) tile_origin(c_i, m0, n0);
+        }
     }
-    __syncthreads();  // every wave is past its last fragment read (and no DMA is outstanding): the stages become the epilogue scratch
-    hgemm_epilogue_lds<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(h3_raw) + wave * (32 * EPI_LD));
 }
 
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant) {
@@ -580,7 +703,8 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
             if (e != hipSuccess) return e;
             attr3.set();
         }
-        const dim3 grid3(((p.N + H3_BN - 1) / H3_BN) * ((p.M + H3_BM - 1) / H3_BM));
+        const int tiles3 = ((p.N + H3_BN - 1) / H3_BN) * ((p.M + H3_BM - 1) / H3_BM);
+        const dim3 grid3(tiles3 < 256 ? tiles3 : 256);   // persistent: one workgroup per CU, tiles blockIdx, blockIdx + 256, ...
         if (out_half) hipLaunchKernelGGL(gemm_f16_dma3_kernel<true>, grid3, dim3(512), H3_SMEM, s, p);
         else hipLaunchKernelGGL(gemm_f16_dma3_kernel<false>, grid3, dim3(512), H3_SMEM, s, p);
         return hipGetLastError();
