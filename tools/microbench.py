@@ -134,6 +134,20 @@ def _bench_gemm_f16(M):
         print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_gemm_f16_resident(M=24000, N=1024):
+    """Is the fp16 GEMM's K loop bound by the latency of its compulsory L2 misses?  Same launches with lda = 0: every row of A is the
+    same 2*K bytes, so A is L1/L2-resident and only W (2-8 MB) streams -- if the loop speeds up a lot, it was waiting for misses."""
+    for variant in (2, 3):
+        for K in (1024, 4096):
+            A = torch.randn(M, K, device="cuda").half()
+            W = (torch.randn(4, N, K, device="cuda") * 0.03).half()
+            bias = torch.zeros(N, device="cuda")
+            C = torch.empty(M, N, device="cuda", dtype=torch.float16)
+            for lda, label in ((K, "normal A"), (0, "A resident (lda = 0)")):
+                us = timeit(lambda i: lib.wt_dbg_gemm_f16_variant(P(A), lda, P(W[i]), P(bias), None, P(C), M, N, K, 0, 1, variant, ST()), 4, iters=5)
+                print(f"variant {variant} M={M} N={N} K={K} {label:22s}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:7.1f} TFLOP/s")
+
+
 def bench_logmel(B=8):
     import time
     import numpy as np
