@@ -44,6 +44,12 @@ int wt_dbg_decode_attention_folded(const float* u, const float* kcache, const fl
 int wt_dbg_attention_then_projection(const float* q, const float* kcache, const float* vcache, float* part, const float* W,
                                      const float* bias, const float* resid, float* Y, int B, int H, int s_cap, int len, int n_split,
                                      void* stream);
+/* the decode step's self-attention -> pair launch with TWO key splits and the merge deferred into BOTH halves of the pair:
+ * a = softmax(q K^T) V over the first `len` cache rows (partials in `part` [B][H][2][68]); h1 = h + Wo.a + bo (Wo [d][d]);
+ * u = Wf.[a ; h] + c (Wf [d][2d]) */
+int wt_dbg_self_attention_then_pair(const float* q, const float* kcache, const float* vcache, float* part, const float* Wo, const float* bo,
+                                    const float* h, float* h1, const float* Wf, const float* c, float* u, int B, int H, int s_cap, int len,
+                                    void* stream);
 /* two skinny GEMMs in one launch: Ya = Xa . Wa^T + bias_a + resid_a ([B][Na], K = Ka) and
  * Yb = [Xb ; Xb2] . Wb^T + bias_b ([B][Nb], K = Kb = 2 * columns of Xb) */
 int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka,

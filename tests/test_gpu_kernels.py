@@ -350,3 +350,31 @@ def test_folded_query_adversarial_rows(lib, B, H, mean, outlier, mixed_gamma):
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("B,H,cap,length", [(8, 16, 448, 447), (8, 16, 448, 1), (8, 16, 448, 2), (3, 8, 448, 100), (1, 16, 64, 33), (8, 6, 448, 200),
+                                            (16, 16, 448, 447), (5, 12, 448, 17)])
+def test_self_attention_two_splits_merged_by_both_halves_of_the_pair(lib, B, H, cap, length):
+    """Decode self-attention over two key splits, merge deferred into the pair launch: the out-projection half merges the partials while
+    it stages its rows, the folded-query half stages the merged `a` for its first K/2 columns and reads h directly for the rest.
+    Against fp64 torch; includes length 1 (the second split has no key) and every batch-width instantiation."""
+    d = 64 * H
+    q = _rand(B, d, seed=51) * 0.5
+    k, v = _rand(B, H, cap, 64, seed=52), _rand(B, H, cap, 64, seed=53)
+    Wo, bo = _rand(d, d, seed=54, scale=d ** -0.5), _rand(d, seed=55)
+    Wf, c = _rand(d, 2 * d, seed=56, scale=(2 * d) ** -0.5), _rand(d, seed=57)
+    h = _rand(B, d, seed=58)
+    qd, kd, vd, Wod, bod, Wfd, cd, hd = (t.cuda() for t in (q, k, v, Wo, bo, Wf, c, h))
+    part = torch.full((B, H, 2, 68), float("nan"), device="cuda")
+    h1 = torch.full((B, d), float("nan"), device="cuda")
+    u = torch.full((B, d), float("nan"), device="cuda")
+    assert lib.wt_dbg_self_attention_then_pair(P(qd), P(kd), P(vd), P(part), P(Wod), P(bod), P(hd), P(h1), P(Wfd), P(cd), P(u), B, H, cap, length,
+                                               _stream()) == 0
+    torch.cuda.synchronize()
+    qh = q.double().view(B, H, 1, 64)
+    a = (torch.softmax(qh @ k.double()[:, :, :length].transpose(-1, -2), -1) @ v.double()[:, :, :length]).reshape(B, d)
+    ref1 = h.double() + a @ Wo.double().T + bo.double()
+    ref2 = torch.cat([a, h.double()], 1) @ Wf.double().T + c.double()
+    assert torch.isfinite(h1).all() and torch.isfinite(u).all()
+    assert (h1.cpu().double() - ref1).abs().max().item() < 3e-5
+    assert (u.cpu().double() - ref2).abs().max().item() < 3e-5

@@ -77,6 +77,26 @@ extern "C" int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float*
     return rc_of(launch_skinny_pair(a, b, (hipStream_t)stream));
 }
 
+extern "C" int wt_dbg_self_attention_then_pair(const float* q, const float* kcache, const float* vcache, float* part, const float* Wo,
+                                              const float* bo, const float* h, float* h1, const float* Wf, const float* c, float* u, int B, int H,
+                                              int s_cap, int len, void* stream) {
+    if (len < 1 || len > s_cap || H * 64 > 1024) return -22;
+    const int d = H * 64;
+    DecAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.kcache = kcache; a.vcache = vcache; a.part = part; a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = 2;
+    a.fixed_len = len; a.nt = 1; a.defer_merge = 1;
+    int rc = rc_of(launch_dec_attn(a, (hipStream_t)stream));
+    if (rc) return rc;
+    SkinnyParams k, k2;
+    memset(&k, 0, sizeof k);
+    memset(&k2, 0, sizeof k2);
+    k.parts = part; k.parts_nsplit = 2; k.parts_H = H; k.W = Wo; k.bias = bo; k.resid = h; k.Y = h1; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = 1;
+    k2.parts = part; k2.parts_nsplit = 2; k2.parts_H = H; k2.X2 = h; k2.x_direct = 1; k2.W = Wf; k2.bias = c; k2.Y = u; k2.B = B; k2.N = d; k2.K = 2 * d;
+    k2.q_scale = 1.f; k2.w_nt = 1;
+    return rc_of(launch_skinny_pair(k, k2, (hipStream_t)stream));
+}
+
 extern "C" int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N,
                                int K, int act, int out_half, void* stream) {
     GemmParams g;

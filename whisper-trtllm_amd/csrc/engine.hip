@@ -516,6 +516,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     case LP_SELF_ATTN:
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
         a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads;
+        a.defer_merge = defer && io.nsplit_self == 2;   // both halves of the pair launch below merge the two partials while staging
         LAUNCH(launch_dec_attn(a, s));
         break;
     case LP_PAIR:
@@ -526,6 +527,10 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
         k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
         k2.X = e->datt; k2.X2 = h; k2.xmode = XMODE_PLAIN; k2.x_direct = 1; k2.W = l.fold_w; k2.bias = l.fold_c;
         k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = e->nt_loads;
+        if (defer && io.nsplit_self == 2) {   // the self-attention context `a` arrives as two split partials per (utterance, head)
+            k.parts = e->part; k.parts_nsplit = 2; k.parts_H = H;
+            k2.parts = e->part; k2.parts_nsplit = 2; k2.parts_H = H;
+        }
         LAUNCH(launch_skinny_pair(k, k2, s));
         break;
     case LP_CROSS_ATTN: {  // cross attention over the encoder memory: K/V already resident
@@ -672,7 +677,15 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         if (nt != e->nt_loads) e->graph_valid = false;
         e->nt_loads = nt;
     }
-    e->nsplit_self = 1;
+    // self attention: two key splits (256 instead of 128 workgroups at batch 8 x 16 heads) with the merge deferred into the pair
+    // launch, while the (utterance, head) pairs leave half the CUs idle; unsplit otherwise.  A/B: WT_NSPLIT_SELF=1|2
+    {
+        const bool can_defer = getenv("WT_NO_DEFER_MERGE") == nullptr && e->d <= 1024;
+        const int want = getenv("WT_NSPLIT_SELF") ? atoi(getenv("WT_NSPLIT_SELF")) : (B * e->H <= 128 ? 2 : 1);
+        const int ns = (want == 2 && can_defer) ? 2 : 1;
+        if (ns != e->nsplit_self) e->graph_valid = false;
+        e->nsplit_self = ns;
+    }
     e->nsplit_cross = getenv("WT_NSPLIT_CROSS") ? atoi(getenv("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
     LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s));  // input of step 0

@@ -137,19 +137,23 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     // rows go out before the first W rows.  (Measured neutral either way: the rows were written by the previous kernel on
     // other XCDs, so they arrive from the memory side together with the first weights, ~1.6-2.2 us after the start;
     // the LayerNorm + staging + barrier that follow are ~0.4-1 us of the launch -- DESIGN.md, timestamp study.)
-    const bool staged = p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2) && !p.parts);
+    // `half_staged`: y = W . [a ; X2] where `a` is the merge of attention split partials (K/2 columns, staged + merged through LDS
+    // like the plain `parts` case) and X2 is read directly: the folded cross-attention query behind a two-split self-attention.
+    const bool half_staged = p.parts != nullptr && p.X2 != nullptr;
+    const int Ks = half_staged ? (p.K >> 1) : p.K;   // columns that go through the LDS staging
+    const bool staged = half_staged || (p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2) && !p.parts));
     if (!staged && row_begin < row_end) wload(0, row_begin);
     if (staged) {
         // every wave of the block needs (a slice of) the same NB whole rows: stage them once per block through LDS.
         // Wave w loads (and LayerNorm-s) rows w and w + NW; after the barrier each wave pulls its slice of all rows.
         bool kfull[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) kfull[v] = (4 * lane + 256 * v) < p.K;
+        for (int v = 0; v < 4; ++v) kfull[v] = (4 * lane + 256 * v) < Ks;
         // gamma/beta are requested together with the rows (not after the statistics) to keep them off the critical path
         float4 g[4], be[4];
         int fcol[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) fcol[v] = min(4 * lane + 256 * v, p.K - 4);
+        for (int v = 0; v < 4; ++v) fcol[v] = min(4 * lane + 256 * v, Ks - 4);
         if (p.xmode == XMODE_LAYERNORM) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -163,7 +167,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             for (int j = 0; j < 2; ++j) {
                 const int b = min(wave + NW * j, p.B - 1);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) xv[j][v] = *reinterpret_cast<const float4*>(p.X + (size_t)b * p.K + fcol[v]);
+                for (int v = 0; v < 4; ++v) xv[j][v] = *reinterpret_cast<const float4*>(p.X + (size_t)b * Ks + fcol[v]);
             }
             if (row_begin < row_end) wload(0, row_begin);
             __builtin_amdgcn_sched_barrier(0);  // all requests are in flight before the first fix-up below
@@ -218,7 +222,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 float sum = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) sum += (xv[j][v].x + xv[j][v].y) + (xv[j][v].z + xv[j][v].w);
-                const float mean = wave_allreduce_sum_d(sum) / p.K;
+                const float mean = wave_allreduce_sum_d(sum) / Ks;
                 float q = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
@@ -226,7 +230,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                         float a = xv[j][v].x - mean, c = xv[j][v].y - mean, e = xv[j][v].z - mean, f = xv[j][v].w - mean;
                         q += (a * a + c * c) + (e * e + f * f);
                     }
-                const float rstd = rsqrtf(wave_allreduce_sum_d(q) / p.K + 1e-5f);
+                const float rstd = rsqrtf(wave_allreduce_sum_d(q) / Ks + 1e-5f);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     xv[j][v].x = (xv[j][v].x - mean) * rstd * g[v].x + be[v].x;
@@ -239,11 +243,24 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&xs[b][4 * lane + 256 * v]) = xv[j][v];
         }
         __syncthreads();
+        if (half_staged && ks0 >= Ks) {  // this wave's K-slice lies in the X2 half (slices never straddle: KS divides K/2): straight from L2
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int v = 0; v < V; ++v)
-                xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][ks0 + 4 * lane + 256 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int v = 0; v < V; ++v) xr[b][v] = *reinterpret_cast<const float4*>(p.X2 + (size_t)min(b, p.B - 1) * Ks + (kcol[v] - Ks));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (!kok[v] || b >= p.B) xr[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][ks0 + 4 * lane + 256 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     } else {
         if (p.X2 == nullptr) {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
 #pragma unroll
@@ -431,7 +448,8 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out, int tg_ove
     if (KS & 3) return hipErrorInvalidValue;
     if (p.K > 1024 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;  // LayerNorm needs whole rows staged in LDS
     if (p.X2 && (p.xmode != XMODE_PLAIN || (p.K & 7))) return hipErrorInvalidValue;
-    if (p.parts && (p.K > 1024 || p.K != p.parts_H * 64 || p.parts_nsplit != 2 || p.X2)) return hipErrorInvalidValue;
+    if (p.parts && !p.X2 && (p.K > 1024 || p.K != p.parts_H * 64 || p.parts_nsplit != 2)) return hipErrorInvalidValue;
+    if (p.parts && p.X2 && (p.K > 2048 || (p.K >> 1) != p.parts_H * 64 || p.parts_nsplit != 2 || (KS > (p.K >> 1)) || ((p.K >> 1) % KS))) return hipErrorInvalidValue;
     const int G = NW / nsplit;
     // row groups (waves x K-splits) per launch: measured per decode step at medium.en B = 8 -- 512: 1.64 ms, 768: 1.53, 1024: 1.475,
     // 1280: 1.478, 1536: 1.49, 2048: 1.51, 3072: 1.51.  1024 = one 4-wave block per CU, each wave streaming two row pairs with
