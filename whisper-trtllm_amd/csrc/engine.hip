@@ -677,11 +677,12 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         if (nt != e->nt_loads) e->graph_valid = false;
         e->nt_loads = nt;
     }
-    // self attention: two key splits (256 instead of 128 workgroups at batch 8 x 16 heads) with the merge deferred into the pair
-    // launch, while the (utterance, head) pairs leave half the CUs idle; unsplit otherwise.  A/B: WT_NSPLIT_SELF=1|2
+    // self attention: unsplit.  Two key splits with the merge deferred into BOTH halves of the pair launch (WT_NSPLIT_SELF=2) are
+    // implemented and tested, and measured a wash at medium.en batch 8: self-attention 9.0 -> 7.6 us at 447 keys, the pair launch
+    // 8.2 -> 9.7 us (its blocks stage and merge two partial sets), 1.659 vs 1.649 ms per step in one A/B on one box.
     {
         const bool can_defer = getenv("WT_NO_DEFER_MERGE") == nullptr && e->d <= 1024;
-        const int want = getenv("WT_NSPLIT_SELF") ? atoi(getenv("WT_NSPLIT_SELF")) : (B * e->H <= 128 ? 2 : 1);
+        const int want = getenv("WT_NSPLIT_SELF") ? atoi(getenv("WT_NSPLIT_SELF")) : 1;
         const int ns = (want == 2 && can_defer) ? 2 : 1;
         if (ns != e->nsplit_self) e->graph_valid = false;
         e->nsplit_self = ns;

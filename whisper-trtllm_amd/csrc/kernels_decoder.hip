@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_pair_kernel(c
 template <int NB, int V, int NW>
 static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out, int tg_override = 0) {
     if (p.B < 1 || p.B > NB || (p.K & 3)) return hipErrorInvalidValue;
-    int nsplit = 1;
+    int nsplit = (p.parts && p.X2) ? 2 : 1;   // half-staged: a wave's K-slice must not straddle the [a ; X2] seam
     while (p.K / nsplit > 256 * V || (p.K % nsplit)) {
         nsplit *= 2;
         if (nsplit > NW) return hipErrorInvalidValue;
