@@ -174,3 +174,21 @@ def test_every_batch_width_is_row_independent(wt, B):
     ids = dec.generate(enc(mel[:B])).cpu().numpy()
     for b in range(B):
         np.testing.assert_array_equal(ids[b], singles[b])
+
+
+@pytest.mark.parametrize("case", ["toy-short_b3", "toy-wide_b2", "tiny_b2"])
+def test_two_split_self_attention_path_matches_golden(wt, case, monkeypatch):
+    """WT_NSPLIT_SELF=2 (off by default: measured a wash): self-attention over two key splits, the merge deferred into both halves of
+    the out-projection + folded-query launch.  Same goldens, same tolerances."""
+    monkeypatch.setenv("WT_NSPLIT_SELF", "2")
+    z, cfg, weights, mel = load_case(case)
+    enc, dec = _engines(wt, cfg, weights)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    B, V, ml = mel.shape[0], cfg["vocab_size"], cfg["max_length"]
+    trace = torch.zeros(B, ml - 1, V, dtype=torch.float32, device="cuda")
+    ids = dec.generate(hidden, logits_trace=trace).cpu().numpy()
+    want = z["ids"]
+    steps = want.shape[1] - 1
+    stride = int(z["logits_stride"])
+    assert np.abs(trace[:, :steps].cpu().numpy()[:, :, ::stride] - z["logits_sub"]).max() < 1e-3
+    np.testing.assert_array_equal(ids, want)
