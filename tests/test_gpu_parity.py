@@ -192,3 +192,25 @@ def test_two_split_self_attention_path_matches_golden(wt, case, monkeypatch):
     stride = int(z["logits_stride"])
     assert np.abs(trace[:, :steps].cpu().numpy()[:, :, ::stride] - z["logits_sub"]).max() < 1e-3
     np.testing.assert_array_equal(ids, want)
+
+
+def test_steps_past_max_length_do_not_touch_the_logits_trace(wt):
+    """Stepwise API: steps enqueued after the stop test fired (here: max_length reached) are no-ops -- in particular the fused-argmax
+    GEMV must not write a trace row past the last one (it would land in the next utterance's first row, or past the buffer)."""
+    z, cfg, weights, mel = load_case("toy-short_b3")
+    enc, dec = _engines(wt, cfg, weights)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    B, V, ml = mel.shape[0], cfg["vocab_size"], cfg["max_length"]
+    guard = 4 * V
+    buf = torch.full((B * (ml - 1) * V + guard,), 777.0, dtype=torch.float32, device="cuda")
+    trace = buf[:B * (ml - 1) * V].view(B, ml - 1, V)
+    dec.begin(hidden, logits_trace=trace)
+    dec.steps(ml - 1)
+    cur, nu, done = dec.poll()
+    assert cur == ml and done
+    snap = buf.clone()
+    dec.steps(5)                      # five more: every kernel of them must leave ids, state and trace alone
+    cur2, _, done2 = dec.poll()
+    assert (cur2, done2) == (ml, True)
+    assert torch.equal(buf, snap) and (buf[-guard:] == 777.0).all()
+    np.testing.assert_array_equal(dec.read_ids(cur).cpu().numpy(), z["ids"])

@@ -294,7 +294,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                                 // epilogue would be an exposed L2 round trip per row pair: measured +10 us on the 51864-row GEMV)
     if (p.ymode == YMODE_ARGMAX) am_mk[0] = p.am_mask[min(row_begin + my_r, p.N - 1)];
     const bool am_at_begin = p.ymode == YMODE_ARGMAX && p.st->cur_len == p.am_begin_index;
-    float* am_tr = (p.ymode == YMODE_ARGMAX && p.am_trace) ? p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N : nullptr;
+    // raw-logits trace row of this step; steps enqueued past the stop test (st->done) or past the trace's last row must not write
+    float* am_tr = (p.ymode == YMODE_ARGMAX && p.am_trace && !p.st->done && p.st->step < p.am_trace_steps)
+                       ? p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N : nullptr;
     const int niter = (rows_per_group + 1) / 2;  // identical for every wave of the block (barriers below)
     // one iteration = two W rows; `cur` (static) is the register buffer holding them, the other one is prefetched
     auto body = [&](auto cur_c, const int it) {
