@@ -69,7 +69,7 @@ hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, co
 // each (row, batch) total in one lane, which applies the epilogue.  When K exceeds a slice, the NW waves of a block
 // split K (nsplit = 2, 4 or 8) and combine through LDS.  Whole activation rows (K <= 1024) are staged -- and
 // LayerNorm-ed -- once per block through LDS.
-template <int NB, int V, int NW, bool W_NT>
+template <int NB, int V, int NW, bool W_NT, bool HALF = false, bool ARGMAX = false>
 __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsplit, const int KS, const int rows_per_group,
                                             const int block) {
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
@@ -127,7 +127,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         if (p.bias) bias_pf = p.bias[n_pf];
         if (p.ymode == YMODE_PLAIN) {
             if (p.resid) resid_pf = p.resid[(size_t)b_pf * p.N + n_pf];
-        } else if (p.ymode == YMODE_QKV_APPEND) {
+        } else if (!ARGMAX && p.ymode == YMODE_QKV_APPEND) {
             self_len_pf = p.st->self_len;
         }
     }
@@ -139,7 +139,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     // the LayerNorm + staging + barrier that follow are ~0.4-1 us of the launch -- DESIGN.md, timestamp study.)
     // `half_staged`: y = W . [a ; X2] where `a` is the merge of attention split partials (K/2 columns, staged + merged through LDS
     // like the plain `parts` case) and X2 is read directly: the folded cross-attention query behind a two-split self-attention.
-    const bool half_staged = p.parts != nullptr && p.X2 != nullptr;
+    // (a compile-time switch: as a run-time branch it pushed every GEMV of the step into register spills -- 0.6-1 us each, 10 us on
+    //  the vocabulary GEMV)
+    constexpr bool half_staged = HALF;
     const int Ks = half_staged ? (p.K >> 1) : p.K;   // columns that go through the LDS staging
     const bool staged = half_staged || (p.K <= 1024 && !(p.xmode == XMODE_PLAIN && (p.x_direct || p.X2) && !p.parts));
     if (!staged && row_begin < row_end) wload(0, row_begin);
@@ -287,16 +289,21 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 if (!kok[v] || b >= p.B) xr[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // YMODE_ARGMAX: running masked maximum of the rows this lane finishes (rows ascend, so the lowest index wins ties)
+    // ARGMAX (a compile-time mode: its state would push the plain GEMVs of the step into register spills): running masked maximum
+    // of the rows this lane finishes (rows ascend, so the lowest index wins ties)
     float am_best = -INFINITY;
     int am_bidx = 0x7fffffff;
     uint8_t am_mk[2] = {0, 0};  // mask bytes of this lane's rows, requested one iteration ahead with the weights (a load in the
                                 // epilogue would be an exposed L2 round trip per row pair: measured +10 us on the 51864-row GEMV)
-    if (p.ymode == YMODE_ARGMAX) am_mk[0] = p.am_mask[min(row_begin + my_r, p.N - 1)];
-    const bool am_at_begin = p.ymode == YMODE_ARGMAX && p.st->cur_len == p.am_begin_index;
-    // raw-logits trace row of this step; steps enqueued past the stop test (st->done) or past the trace's last row must not write
-    float* am_tr = (p.ymode == YMODE_ARGMAX && p.am_trace && !p.st->done && p.st->step < p.am_trace_steps)
-                       ? p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N : nullptr;
+    bool am_at_begin = false;
+    float* am_tr = nullptr;
+    if constexpr (ARGMAX) {
+        am_mk[0] = p.am_mask[min(row_begin + my_r, p.N - 1)];
+        am_at_begin = p.st->cur_len == p.am_begin_index;
+        // raw-logits trace row of this step; steps enqueued past the stop test (st->done) or past the trace's last row must not write
+        if (p.am_trace && !p.st->done && p.st->step < p.am_trace_steps)
+            am_tr = p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N;
+    }
     const int niter = (rows_per_group + 1) / 2;  // identical for every wave of the block (barriers below)
     // one iteration = two W rows; `cur` (static) is the register buffer holding them, the other one is prefetched
     auto body = [&](auto cur_c, const int it) {
@@ -305,7 +312,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         const bool active = row < row_end;
         if (active && row + 2 < row_end) {
             wload(cur ^ 1, row + 2);
-            if (p.ymode == YMODE_ARGMAX) am_mk[cur ^ 1] = p.am_mask[min(row + 2 + my_r, p.N - 1)];
+            if constexpr (ARGMAX) am_mk[cur ^ 1] = p.am_mask[min(row + 2 + my_r, p.N - 1)];
         }
         float out = 0.f;
         if (active) {
@@ -360,13 +367,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         const int n = row + my_r;
         if (do_epi && n < row_end && my_b < p.B) {
             float v = total + (it == 0 ? bias_pf : (p.bias ? p.bias[n] : 0.f));
-            if (p.ymode == YMODE_PLAIN) {
-                v *= p.q_scale;
-                if (p.act) v = gelu_erf_d(v);
-                const size_t off = (size_t)my_b * p.N + n;
-                if (p.resid) v += it == 0 ? resid_pf : p.resid[off];
-                p.Y[off] = v;
-            } else if (p.ymode == YMODE_ARGMAX) {  // logits processors (Suppress -> SuppressAtBegin) + running argmax, logits_process.py:1281-1311
+            if constexpr (ARGMAX) {  // logits processors (Suppress -> SuppressAtBegin) + running argmax, logits_process.py:1281-1311
                 v *= p.q_scale;
                 if (am_tr) am_tr[n] = v;
                 const uint8_t mk = am_mk[cur];
@@ -375,6 +376,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                     am_best = v;
                     am_bidx = n;
                 }
+            } else if (p.ymode == YMODE_PLAIN) {
+                v *= p.q_scale;
+                if (p.act) v = gelu_erf_d(v);
+                const size_t off = (size_t)my_b * p.N + n;
+                if (p.resid) v += it == 0 ? resid_pf : p.resid[off];
+                p.Y[off] = v;
             } else {  // fused q|k|v projection: q (scaled) -> Y, k/v rows appended in place at index self_len
                 const int third = n / p.d_model, nn = n - third * p.d_model;
                 if (third == 0) {
@@ -391,7 +398,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         body(std::integral_constant<int, 0>{}, it);
         if (it + 1 < niter) body(std::integral_constant<int, 1>{}, it + 1);
     }
-    if (p.ymode == YMODE_ARGMAX) {
+    if constexpr (ARGMAX) {
         // one (max, argmax) per batch row and workgroup: output lanes -> LDS (the activation staging area is free by now) ->
         // thread b scans the NW x 2 candidates of batch row b in a fixed order
         __syncthreads();
@@ -423,19 +430,19 @@ struct SkinnyPlan {
     int nsplit, KS, rows_per_group, grid;
 };
 
-template <int NB, int V, int NW, bool W_NT>
+template <int NB, int V, int NW, bool W_NT, bool ARGMAX = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
                                                                              const int rows_per_group) {
-    skinny_body<NB, V, NW, W_NT>(p, nsplit, KS, rows_per_group, blockIdx.x);
+    skinny_body<NB, V, NW, W_NT, false, ARGMAX>(p, nsplit, KS, rows_per_group, blockIdx.x);
 }
 
 // Two GEMMs that depend on the same predecessor share ONE launch (the self-attention out-projection and the folded
 // cross-attention query): blocks [0, pa.grid) run `a`, the rest run `b`.  The branch is block-uniform.
-template <int NB, int V, int NW>
+template <int NB, int V, int NW, bool HALF_B>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_pair_kernel(const SkinnyParams a, const SkinnyPlan pa,
                                                                              const SkinnyParams b, const SkinnyPlan pb) {
     if ((int)blockIdx.x < pa.grid) skinny_body<NB, V, NW, true>(a, pa.nsplit, pa.KS, pa.rows_per_group, blockIdx.x);
-    else skinny_body<NB, V, NW, true>(b, pb.nsplit, pb.KS, pb.rows_per_group, blockIdx.x - pa.grid);
+    else skinny_body<NB, V, NW, true, HALF_B>(b, pb.nsplit, pb.KS, pb.rows_per_group, blockIdx.x - pa.grid);
 }
 
 template <int NB, int V, int NW>
@@ -474,7 +481,10 @@ static hipError_t skinny_smem_attr() {
     if (!attr_set.get() && smem > 48 * 1024) {
         for (const void* f : {reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true>),
                               reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false>),
-                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW>)}) {
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true, true>),
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false, true>),
+                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, false>),
+                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, true>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return e;
         }
@@ -490,7 +500,10 @@ static hipError_t skinny_launch_cfg(const SkinnyParams& p, hipStream_t s) {
     if (e == hipSuccess) e = skinny_smem_attr<NB, V, NW>();
     if (e != hipSuccess) return e;
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
-    if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
+    if (p.ymode == YMODE_ARGMAX) {
+        if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
+    } else if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
     else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
     return hipGetLastError();
 }
@@ -511,7 +524,9 @@ static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, 
     if (e == hipSuccess) e = skinny_smem_attr<NB, V, NW>();
     if (e != hipSuccess) return e;
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
-    hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW>), dim3(pa.grid + pb.grid), dim3(64 * NW), smem, s, a, pa, b, pb);
+    if (a.parts && a.X2) return hipErrorInvalidValue;   // the half-staged form exists for the second GEMV of a pair only
+    if (b.parts && b.X2) hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, true>), dim3(pa.grid + pb.grid), dim3(64 * NW), smem, s, a, pa, b, pb);
+    else hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, false>), dim3(pa.grid + pb.grid), dim3(64 * NW), smem, s, a, pa, b, pb);
     return hipGetLastError();
 }
 
@@ -524,6 +539,7 @@ int skinny_grid(const SkinnyParams& p) {  // workgroups launch_skinny will use f
 
 hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
     if (p.B < 1 || p.B > 16 || (p.K & 3)) return hipErrorInvalidValue;
+    if (p.parts && p.X2) return hipErrorInvalidValue;   // half-staged: pair launches only
     if (p.ymode == YMODE_ARGMAX && (!p.am_mask || !p.am_val || !p.am_idx || p.am_ld < skinny_grid(p) || p.resid || p.act)) return hipErrorInvalidValue;
     if (p.B <= 2) return skinny_launch_cfg<2, 4, 4>(p, s);
     if (p.B <= 4) return skinny_launch_cfg<4, 4, 4>(p, s);
