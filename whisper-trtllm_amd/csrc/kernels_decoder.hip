@@ -820,22 +820,40 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
     __shared__ int s_pos;
     __shared__ int s_unf[16];
     DecState* st = p.st;
-    if (st->done) return;
-    const int tid = threadIdx.x, cur_len = st->cur_len, step = st->step;
+    const int tid = threadIdx.x;
     // final masked argmax of every row over its n_parts partial results (lowest index on ties).  All rows at once: a group of
     // `lpb` lanes per row (32 at B <= 8, 16 at B <= 16), every load of the block in flight together -- the partials were written by
     // other XCDs a kernel ago, so this is one memory round trip; row by row it was B of them (measured 14 us per step at B = 8).
+    // The candidates do not depend on DecState: the first 8 x lpb of a row are requested BEFORE it is read (one dependent round
+    // trip fewer), by unconditional clamped loads.
+    const int lpb = p.B <= 4 ? 64 : p.B <= 8 ? 32 : 16;
+    const int b = tid / lpb, l = tid % lpb;
+    const size_t pbase = (size_t)min(b, p.B - 1) * p.n_parts;
+    float pv[8];
+    int pi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = min(l + k * lpb, p.n_parts - 1);
+        pv[k] = p.part_val[pbase + i];
+        pi[k] = p.part_idx[pbase + i];
+    }
+    const int unf = p.unfinished[min(b, p.B - 1)];
+    const int done = st->done, cur_len = st->cur_len, step = st->step;
+    if (done) return;   // block-uniform: steps enqueued past the stop test are no-ops
     {
-        const int lpb = p.B <= 4 ? 64 : p.B <= 8 ? 32 : 16;
-        const int b = tid / lpb, l = tid % lpb;
+        const int forced = p.forced[cur_len];                          // ForceTokensLogitsProcessor
         float best = -INFINITY;
         int bidx = 0x7fffffff;
-        const int forced = p.forced[cur_len];                          // ForceTokensLogitsProcessor (requested with the partials)
-        const int unf = p.unfinished[min(b, p.B - 1)];
         if (b < p.B) {
-            for (int i = l; i < p.n_parts; i += lpb) {
-                const float v = p.part_val[(size_t)b * p.n_parts + i];
-                const int ix = p.part_idx[(size_t)b * p.n_parts + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (l + k * lpb < p.n_parts && (pv[k] > best || (pv[k] == best && pi[k] < bidx))) {
+                    best = pv[k];
+                    bidx = pi[k];
+                }
+            for (int i = l + 8 * lpb; i < p.n_parts; i += lpb) {
+                const float v = p.part_val[pbase + i];
+                const int ix = p.part_idx[pbase + i];
                 if (v > best || (v == best && ix < bidx)) {
                     best = v;
                     bidx = ix;
