@@ -379,3 +379,18 @@ def test_run_py_compare_ignores_batch_padding(wt, tmp_path):
     import json
     got = np.array(json.load(open(tmp_path / "ids.json")))
     np.testing.assert_array_equal(got, z["ids"])          # and the fast path reproduces the reference-recorded golden (early-EOS row padded)
+
+
+def test_unfused_argmax_path_still_matches_golden(wt, tmp_path):
+    """WT_NO_FUSED_ARGMAX=1 (A/B switch, read once per process): logits to HBM + greedy_select_kernel + greedy_finish_kernel.
+    Run in a fresh process through examples/whisper/run.py; ids must equal the reference-recorded golden (early-EOS row padded)."""
+    import json
+    import subprocess
+    z, cfg, weights, mel = load_case("toy-short-eos1_b3")
+    eng = _write_engine_dir(wt, tmp_path, cfg, weights)
+    env = dict(os.environ, WT_NO_FUSED_ARGMAX="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "whisper", "run.py"), "--engine_dir", str(eng), "--synthetic", "3",
+                          "--synthetic_start", str(int(z["mel_index"])), "--dump_ids", str(tmp_path / "ids.json")],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    np.testing.assert_array_equal(np.array(json.load(open(tmp_path / "ids.json"))), z["ids"])
