@@ -530,77 +530,10 @@ static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, 
     return hipGetLastError();
 }
 
-// ---- batch 9..16 as TWO 8-row halves in one launch -------------------------------------------------------------------------------
-// The 16-row instantiation (<16, 2, 8>: half-width K-slices, every GEMV K-split over wave pairs with an LDS combine and a barrier per
-// row pair) runs 0.9-1.4 us slower per launch than the 8-row one, 16 us on the vocabulary GEMV.  Instead: the 8-row kernel, once per
-// half of the batch, in ONE launch -- workgroups t and t + 8 (the same XCD under round-robin placement) run the two halves of the same
-// weight rows with DEFAULT-policy loads, so the second reader is served by that XCD's L2 (2.1 MB of a 16.8 MB GEMV per XCD: it fits)
-// and HBM still streams every weight once.  Placement is a speed assumption only: a wrong guess reads the weights twice.
-static bool dual_enabled() {
-    static const bool on = getenv("WT_NO_DUAL") == nullptr;
-    return on;
-}
-static void split_half(const SkinnyParams& p, SkinnyParams& h, const int half) {
-    h = p;
-    const int b0 = 8 * half;
-    h.B = half ? p.B - 8 : 8;
-    h.w_nt = 0;
-    if (h.X) h.X += (size_t)b0 * (p.X2 ? (p.K >> 1) : p.K);
-    if (h.X2) h.X2 += (size_t)b0 * (p.K >> 1);
-    if (h.parts) h.parts += (size_t)b0 * p.parts_H * p.parts_nsplit * PART_STRIDE;
-    if (h.resid) h.resid += (size_t)b0 * p.N;
-    if (p.ymode == YMODE_QKV_APPEND) {
-        const size_t per_b = (size_t)(p.d_model >> 6) * p.s_cap * HEAD_DIM;
-        h.Y += (size_t)b0 * p.d_model;
-        h.kcache += b0 * per_b;
-        h.vcache += b0 * per_b;
-    } else if (p.ymode == YMODE_ARGMAX) {
-        h.am_val += (size_t)b0 * p.am_ld;
-        h.am_idx += (size_t)b0 * p.am_ld;
-        if (h.am_trace) h.am_trace += (size_t)b0 * p.am_trace_steps * p.N;
-    } else if (h.Y) {
-        h.Y += (size_t)b0 * p.N;
-    }
-}
-
-template <bool W_NT, bool ARGMAX>
-__global__ __launch_bounds__(256, 2) void skinny_dual_kernel(const SkinnyParams p0, const SkinnyParams p1, const int nsplit, const int KS,
-                                                             const int rows_per_group, const int grid1) {
-    const int t = blockIdx.x, half = (t >> 3) & 1, i = ((t >> 4) << 3) | (t & 7);   // t and t + 8: the two halves of workgroup i
-    if (i >= grid1) return;                                                          // padding of the last group of 8 (block-uniform)
-    if (half) skinny_body<8, 4, 4, W_NT, false, ARGMAX>(p1, nsplit, KS, rows_per_group, i);
-    else skinny_body<8, 4, 4, W_NT, false, ARGMAX>(p0, nsplit, KS, rows_per_group, i);
-}
-
-static hipError_t skinny_launch_dual(const SkinnyParams& p, hipStream_t s) {
-    SkinnyParams p0, p1;
-    split_half(p, p0, 0);
-    split_half(p, p1, 1);
+int skinny_grid(const SkinnyParams& p) {  // workgroups launch_skinny will use for p (the column count of am_val / am_idx)
     SkinnyPlan pl;
-    hipError_t e = skinny_plan<8, 4, 4>(p0, &pl);
-    if (e == hipSuccess) e = skinny_smem_attr<8, 4, 4>();
-    constexpr int smem = (8 * 1024 + 2 * 4 * 2 * 8) * (int)sizeof(float);
-    static PerDeviceFlag attr_set;
-    if (e == hipSuccess && !attr_set.get()) {
-        for (const void* f : {reinterpret_cast<const void*>(skinny_dual_kernel<false, false>), reinterpret_cast<const void*>(skinny_dual_kernel<false, true>)}) {
-            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) return e;
-        }
-        attr_set.set();
-    }
-    if (e != hipSuccess) return e;
-    const int grid = 2 * ((pl.grid + 7) & ~7);
-    if (p.ymode == YMODE_ARGMAX) hipLaunchKernelGGL((skinny_dual_kernel<false, true>), dim3(grid), dim3(256), smem, s, p0, p1, pl.nsplit, pl.KS, pl.rows_per_group, pl.grid);
-    else hipLaunchKernelGGL((skinny_dual_kernel<false, false>), dim3(grid), dim3(256), smem, s, p0, p1, pl.nsplit, pl.KS, pl.rows_per_group, pl.grid);
-    return hipGetLastError();
-}
-
-int skinny_grid(const SkinnyParams& p) {  // workgroups PER BATCH ROW launch_skinny will use for p (the column count of am_val / am_idx)
-    SkinnyPlan pl;
-    SkinnyParams q = p;
-    if (p.B > 8 && dual_enabled()) q.B = 8;
-    hipError_t e = q.B <= 2 ? skinny_plan<2, 4, 4>(q, &pl) : q.B <= 4 ? skinny_plan<4, 4, 4>(q, &pl) : q.B <= 8 ? skinny_plan<8, 4, 4>(q, &pl)
-                                                                                                   : skinny_plan<16, 2, 8>(q, &pl);
+    hipError_t e = p.B <= 2 ? skinny_plan<2, 4, 4>(p, &pl) : p.B <= 4 ? skinny_plan<4, 4, 4>(p, &pl) : p.B <= 8 ? skinny_plan<8, 4, 4>(p, &pl)
+                                                                                                   : skinny_plan<16, 2, 8>(p, &pl);
     return e == hipSuccess ? pl.grid : -1;
 }
 
@@ -611,8 +544,7 @@ hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s) {
     if (p.B <= 2) return skinny_launch_cfg<2, 4, 4>(p, s);
     if (p.B <= 4) return skinny_launch_cfg<4, 4, 4>(p, s);
     if (p.B <= 8) return skinny_launch_cfg<8, 4, 4>(p, s);
-    if (dual_enabled()) return skinny_launch_dual(p, s);   // two 8-row halves sharing the weights through L2
-    return skinny_launch_cfg<16, 2, 8>(p, s);              // 16 rows: half-width K-slices, 8 waves per block
+    return skinny_launch_cfg<16, 2, 8>(p, s);  // 16 rows: half-width K-slices, 8 waves per block
 }
 
 hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s) {
