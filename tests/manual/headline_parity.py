@@ -1,3 +1,4 @@
+# Manual GPU check (imports the oracle, hence under tests/): python tests/manual/headline_parity.py
 import sys, os, time
 sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "oracle")]
 import numpy as np, torch
