@@ -149,18 +149,10 @@ def bench_gemm_f16_resident(M=24000, N=1024):
 
 
 def bench_logmel(B=8):
-    import time
-    import numpy as np
     fe = w.audio.LogMelFrontend()
     wav = torch.randn(B, 480000, device="cuda") * 0.1
     us = timeit(lambda i: fe(wav), 1, iters=5)
     print(f"log-mel front-end, {B} x 30 s on the GPU: {us / 1e3:8.3f} ms  ({B * 30 / (us * 1e-6):.0f} audio-s/s)")
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-    import cpu_ref
-    x = wav[0].cpu().numpy()
-    t0 = time.perf_counter()
-    cpu_ref.log_mel_spectrogram(x)
-    print(f"oracle (numpy restatement of the reference's feature extractor), 1 x 30 s on the CPU: {(time.perf_counter() - t0) * 1e3:8.1f} ms")
 
 
 def bench_enc_attn(B=8, S=1500, H=16):
