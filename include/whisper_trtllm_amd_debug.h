@@ -15,6 +15,10 @@ extern "C" {
 /* C[M][N] = act(A[M][K(lda)] W[N][K]^T + bias) (+ resid); act: 0 none, 1 erf-GELU */
 int wt_dbg_gemm(const float* A, int lda, const float* W, const float* bias, const float* resid, float* C, int M, int N,
                 int K, int act, void* stream);
+/* the same launch from a probe build of the LDS-DMA kernel (K % 16 == 0): every workgroup leaves {HW_ID, XCC_ID, wall clock (100 MHz) at
+ * entry, first tile landed, K loop done, stores drained, last store issued, 0} in stamps[workgroup][8] (tools/gemm_stamps.py) */
+int wt_dbg_gemm_stamps(const float* A, int lda, const float* W, const float* bias, const float* resid, float* C, int M, int N, int K,
+                       int act, long long* stamps, void* stream);
 /* fp16 operands (A [M][K(lda)], W [N][K] as IEEE half), fp32 accumulate; C is half when out_half else float */
 int wt_dbg_gemm_f16(const void* A, int lda, const void* W, const float* bias, const float* resid, void* C, int M, int N, int K,
                     int act, int out_half, void* stream);

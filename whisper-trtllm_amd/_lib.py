@@ -20,7 +20,7 @@ EXPORTS = [
     "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
-DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_decode_attention",
+DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_decode_attention",
                  "wt_dbg_decode_attention_folded", "wt_dbg_skinny_pair", "wt_dbg_attention_then_projection", "wt_dbg_self_attention_then_pair"]
 
 
@@ -98,6 +98,7 @@ def load():
     lib.wt_decoder_time_kernel.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_float), c_void_p]
     P, I, F = c_void_p, c_int, c_float
     lib.wt_dbg_gemm.argtypes = [P, I, P, P, P, P, I, I, I, I, P]
+    lib.wt_dbg_gemm_stamps.argtypes = [P, I, P, P, P, P, I, I, I, I, P, P]
     lib.wt_dbg_gemm_f16.argtypes = [P, I, P, P, P, P, I, I, I, I, I, P]
     lib.wt_dbg_gemm_f16_variant.argtypes = [P, I, P, P, P, P, I, I, I, I, I, I, P]
     lib.wt_dbg_layernorm.argtypes = [P, P, P, P, I, I, P]

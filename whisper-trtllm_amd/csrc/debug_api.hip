@@ -16,6 +16,14 @@ extern "C" int wt_dbg_gemm(const float* A, int lda, const float* W, const float*
     g.c_rows_per_batch = M; g.M = M; g.N = N; g.K = K; g.act = act;
     return rc_of(launch_gemm_f32(g, (hipStream_t)stream));
 }
+extern "C" int wt_dbg_gemm_stamps(const float* A, int lda, const float* W, const float* bias, const float* resid, float* C, int M,
+                                  int N, int K, int act, long long* stamps, void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.lda = lda; g.a_rows_per_batch = M; g.W = W; g.bias = bias; g.resid = resid; g.C = C; g.ldc = N;
+    g.c_rows_per_batch = M; g.M = M; g.N = N; g.K = K; g.act = act; g.dbg_stamps = stamps;
+    return rc_of(launch_gemm_f32(g, (hipStream_t)stream));
+}
 extern "C" int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream) {
     return rc_of(launch_layernorm(x, w, b, y, rows, d, (hipStream_t)stream));
 }

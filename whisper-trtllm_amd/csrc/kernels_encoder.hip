@@ -180,6 +180,97 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     }
 }
 
+// Fast epilogue for a wave whose 64x64 sub-tile lies wholly inside C: no bounds masks, the optional operands are compile-time, and the
+// residual / position loads run two row groups ahead of their use in straight-line code, so the only waits are counted vmcnt(N) for
+// loads -- never for the stores.  (gfx9 has ONE counter for loads and stores: in the generic epilogue above every `p.resid ? load : 0`
+// becomes a branch whose join waits vmcnt(0), i.e. for the round trip of all stores issued so far; measured per workgroup, its stores
+// took 13 us to ISSUE alone on a CU and 60 us beside other workgroups' K loops -- a third of a K = 1024 tile's life.)
+template <bool RESID, bool ACT, bool POS, bool KV>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                                   const int wc, const int l31, const int hh) {
+    const int mw = m0 + wr * 64, rpb = p.c_rows_per_batch;
+    const int cb_w = mw / rpb, cr_w = mw - cb_w * rpb;                 // wave-uniform: one division
+    int nn[2], col[2];
+    float bv[2];
+    float* base[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+        bv[tj] = p.bias ? p.bias[nn[tj]] : 0.f;
+        if (KV) {
+            const int dkv = p.kv_heads * HEAD_DIM, which = nn[tj] / dkv, r2 = nn[tj] - which * dkv, h = r2 / HEAD_DIM;
+            col[tj] = h * p.kv_cap * HEAD_DIM + (r2 - h * HEAD_DIM);
+            base[tj] = which ? p.C2 : p.C;
+        } else {
+            col[tj] = nn[tj];
+            base[tj] = p.C;
+        }
+    }
+    const int row_stride = KV ? HEAD_DIM : p.ldc;
+    const int batch_stride = KV ? p.kv_heads * p.kv_cap * HEAD_DIM : (int)p.c_batch_stride;
+    const int row_add = KV ? p.kv_seq_off : 0;
+    // group g = (ti, rq): rows o = ti*32 + 8*rq + 4*hh + ri, ri < 4
+    auto row_of = [&](const int g, const int ri, int& cr) -> int {
+        const int o = (g >> 2) * 32 + 8 * (g & 3) + 4 * hh + ri;
+        cr = cr_w + o;
+        const bool over = cr >= rpb;                                  // a 64-row span crosses at most one batch boundary (rpb >= 64)
+        cr -= over ? rpb : 0;
+        return (cb_w + (over ? 1 : 0)) * batch_stride + (cr + row_add) * row_stride;
+    };
+    float rv[2][8], pv[2][8];
+    auto fetch = [&](const int g) {
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            int cr;
+            const int off = row_of(g, ri, cr);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                if (RESID) rv[g & 1][ri * 2 + tj] = p.resid[off + col[tj]];
+                if (POS) pv[g & 1][ri * 2 + tj] = p.pos[cr * p.N + nn[tj]];
+            }
+        }
+    };
+    if (RESID || POS) { fetch(0); fetch(1); }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float v[8];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                float x = acc[g >> 2][tj][(g & 3) * 4 + ri] + bv[tj];
+                if (ACT) x = gelu_erf(x);
+                if (POS) x += pv[g & 1][ri * 2 + tj];
+                if (RESID) x += rv[g & 1][ri * 2 + tj];
+                v[ri * 2 + tj] = x;
+            }
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            int cr;
+            const int off = row_of(g, ri, cr);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) base[tj][off + col[tj]] = v[ri * 2 + tj];
+        }
+        if ((RESID || POS) && g + 2 < 8) fetch(g + 2);
+    }
+}
+
+// Epilogue dispatch: the fast form for interior sub-tiles of the operand combinations the engines use, the generic one otherwise.
+__device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                                  const int wc, const int l31, const int hh) {
+    const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * 64 + 64 <= p.N && p.c_rows_per_batch >= 64 && p.epi_fits32;
+    if (interior && p.epi == EPI_ROWMAJOR && !p.pos) {
+        if (p.resid && !p.act) return gemm_epilogue_fast<true, false, false, false>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (!p.resid && p.act) return gemm_epilogue_fast<false, true, false, false>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (!p.resid && !p.act) return gemm_epilogue_fast<false, false, false, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    } else if (interior && p.epi == EPI_ROWMAJOR && p.pos && p.act && !p.resid) {
+        return gemm_epilogue_fast<false, true, true, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    } else if (interior && p.epi == EPI_KV_HEADS && !p.pos && !p.act && !p.resid) {
+        return gemm_epilogue_fast<false, false, false, true>(p, acc, m0, n0, wr, wc, l31, hh);
+    }
+    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+}
+
 // ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
 // 128x128 block tile, 4 waves in a 2x2 grid, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32 (exact fp32,
 // 64 FLOP/clk/SIMD), K-step 16 (32 selectable).  A and W tiles are staged global -> registers -> LDS (rows padded by 4 floats so the
@@ -284,7 +375,7 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
         __syncthreads();
     }
 
-    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+    gemm_epilogue_any(p, acc, m0, n0, wr, wc, l31, hh);
 }
 
 // The same GEMM with the tiles staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPR staging, no ds_write),
@@ -292,11 +383,17 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
 // tile is UNPADDED, [row][4 chunks of 4 floats], and bank conflicts of the fragment reads are avoided by an XOR swizzle
 // applied on both sides (cdna guide §5.4 rule 21): the lane that fills LDS chunk position `pos` of row r fetches global
 // chunk pos ^ ((r >> 2) & 3); a fragment read of chunk c of row r reads position c ^ ((r >> 2) & 3).  Rows 4a+b, a,b < 4,
-// then cover all 16 sixteen-byte bank groups for every c.  Two 16 KiB stages; the DMA of tile kt+1 is issued right
-// after the barrier that opens tile kt and lands while tile kt is multiplied.
-__global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p) {
+// then cover all 16 sixteen-byte bank groups for every c.  Three 16 KiB stages (48 KiB -> three workgroups per CU; four waves per
+// SIMD sustain LESS MFMA throughput than three, tools/probes/mfma_rate.hip: 125 vs 155 TFLOP/s of pure v_mfma_f32_32x32x2_f32):
+// the DMA of tile kt+2 is issued right after the barrier that opens tile kt, and the wait at the top of a step is counted
+// (vmcnt(4): tile kt+1's four DMA instructions may still be in flight).
+template <bool STAMP>
+__global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p) {
+    constexpr int STAGES = 3;
     constexpr int BK = 16;
-    __shared__ __attribute__((aligned(1024))) float smem[2][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
+    long long t_start = 0, t_first = 0, t_loop = 0;   // probe build: wall-clock stamps (100 MHz)
+    if (STAMP) t_start = wall_clock64();
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -352,12 +449,20 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p
 
     const int nk = p.K / BK;
     dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt has landed
-        __syncthreads();                                   // ... everyone's has, and nobody still reads the other stage
+        // this wave's share of tile kt has landed (with three stages tile kt+1's four DMA instructions may still be in flight)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... everyone's has, and nobody still reads the stage refilled next (the fragment reads of step kt-1 were waited for
+        // before its MFMAs).  A raw s_barrier: __syncthreads() would add a vmcnt(0) fence and undo the counted wait.
+        __builtin_amdgcn_s_barrier();
+        if (STAMP && kt == 0) t_first = wall_clock64();
         const float* As = &smem[cur][0][0];
         const float* Ws = &smem[cur][1][0];
+        const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
+        const int fill = cur == 0 ? STAGES - 1 : cur - 1;                          // the stage read during step kt-1
         // (pinning all eight fragment reads above the first MFMA with sched_barrier measured 7 % SLOWER: the compiler's own
         //  interleaving of the second four reads with the first sixteen MFMAs is the better schedule)
 #pragma unroll
@@ -367,7 +472,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
-            if (q == 0 && kt + 1 < nk) dma(cur ^ 1, kt + 1);  // after the first fragment reads are on their way
+            if (q == 0 && kt + STAGES - 1 < nk) dma(fill, kt + STAGES - 1);  // after the first fragment reads are on their way
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
@@ -376,12 +481,35 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_dma_kernel(const GemmParams p
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
             }
         }
+        cur = nxt;
     }
-    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+    if (STAMP) t_loop = wall_clock64();
+    gemm_epilogue_any(p, acc, m0, n0, wr, wc, l31, hh);
+    if (STAMP) {
+        const long long t_issued = wall_clock64();           // every store of this wave issued (the product kernel ends here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            long long* o = p.dbg_stamps + (long long)blockIdx.x * 8;
+            o[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));   // HW_REG_HW_ID
+            o[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID
+            o[2] = t_start; o[3] = t_first; o[4] = t_loop; o[5] = wall_clock64(); o[6] = t_issued; o[7] = 0;
+        }
+    }
 }
 
-hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
+hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    {
+        // the fast epilogue indexes C / resid / pos with 32-bit element offsets
+        const long long batches = (p.M + (long long)p.c_rows_per_batch - 1) / (p.c_rows_per_batch > 0 ? p.c_rows_per_batch : 1) + 1;
+        const long long reach = p.epi == EPI_KV_HEADS
+                                    ? batches * p.kv_heads * p.kv_cap * HEAD_DIM + ((long long)p.c_rows_per_batch + p.kv_seq_off) * HEAD_DIM
+                                    : batches * (p.c_batch_stride > 0 ? p.c_batch_stride : 0) + ((long long)p.c_rows_per_batch + 1) * p.ldc + p.N;
+        const long long pos_reach = ((long long)p.c_rows_per_batch + 1) * p.N;
+        p.epi_fits32 = reach < (1ll << 31) && pos_reach < (1ll << 31) && p.c_batch_stride >= 0 && p.ldc >= 0;
+    }
     if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3) || p.c_rows_per_batch < 1 || p.a_rows_per_batch < 1) return hipErrorInvalidValue;
     static PerDeviceFlag attr_set;
     static int force_bk = 0;
@@ -404,7 +532,10 @@ hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s) {
     if (force_bk == 16 || force_bk == 32) bk = force_bk;
     static const bool no_dma = getenv("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
     if (!no_dma && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
-        hipLaunchKernelGGL(gemm_f32_dma_kernel, dim3(tiles), dim3(256), 0, s, p);
+    {
+        if (p.dbg_stamps) hipLaunchKernelGGL(gemm_f32_dma_kernel<true>, dim3(tiles), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemm_f32_dma_kernel<false>, dim3(tiles), dim3(256), 0, s, p);
+    }
     else if (bk == 16) hipLaunchKernelGGL(gemm_f32_kernel<16>, dim3(tiles), dim3(256), gemm_smem_bytes<16>(), s, p);
     else hipLaunchKernelGGL(gemm_f32_kernel<32>, dim3(tiles), dim3(256), gemm_smem_bytes<32>(), s, p);
     return hipGetLastError();

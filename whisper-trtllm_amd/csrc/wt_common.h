@@ -34,6 +34,8 @@ struct GemmParams {
     int act;              // 0 none, 1 exact-erf GELU
     int epi;              // 0 row-major, 1 split into K/V head caches [b][h][s_cap][64]
     int kv_heads, kv_cap, kv_seq_off;  // EPI_KV_HEADS: heads per row, cache capacity (rows), first row to write
+    int epi_fits32;                    // set by launch_gemm_f32: every output / residual / position offset fits an int (fast epilogue)
+    long long* dbg_stamps;             // probe builds only (wt_dbg_gemm_stamps): [tiles][8] placement + wall-clock stamps per workgroup
 };
 enum { EPI_ROWMAJOR = 0, EPI_KV_HEADS = 1 };
 
