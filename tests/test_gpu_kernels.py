@@ -51,6 +51,28 @@ def test_gemm(lib, M, N, K, act, use_res):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K,act,use_res", [
+    # more than one round of 128x128 tiles (> 768 workgroups) with 3 (= pipeline depth), 4 and 16 K-steps per tile and ragged last
+    # tile row / column: interior sub-tiles take the branch-free epilogue, edge sub-tiles the generic one, in the same launch;
+    # every epilogue kind wt_dbg_gemm can reach (plain, GELU, residual in place)
+    (4000, 3200, 48, 0, False), (4100, 3210, 64, 1, False), (5000, 2600, 256, 0, True), (12000, 1100, 64, 0, True)])
+def test_gemm_many_tiles(lib, M, N, K, act, use_res):
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    R = _rand(M, N, seed=4) if use_res else None
+    ref = F.linear(A.double(), W.double(), b.double())
+    if act:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    for rep in range(2):
+        C = R.cuda().clone() if use_res else torch.full((M, N), float("nan"), device="cuda")
+        assert lib.wt_dbg_gemm(P(Ad), K, P(Wd), P(bd), P(C) if use_res else None, P(C), M, N, K, act, _stream()) == 0
+        torch.cuda.synchronize()
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (rep, err)
+
+
 @pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
     (128, 128, 64, 0, 0, False), (200, 136, 240, 1, 1, False), (1500, 384, 384, 0, 0, True), (97, 1000, 1536, 1, 1, False),
     (3000, 128, 240, 1, 1, False), (33, 51, 8, 0, 0, False), (1024, 3072, 1024, 0, 0, True),

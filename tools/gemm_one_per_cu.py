@@ -1,5 +1,6 @@
 """fp32 GEMM K loop with exactly 1, 2 or 3 workgroups per CU (256, 512, 768 tiles of 128x128, K = 4096): how close does ONE wave per SIMD
-get to the MFMA rate?  Run under WT_GEMM_STAGES=2|3|13 for the loop variants."""
+get to the MFMA rate?  (Round 2: 117-119 TFLOP/s with 1 workgroup per CU, 130-132 with 2 or 3; a software-pipelined loop that kept
+one wave's MFMA queue full over the barrier reached 123 at 1 per CU and LOST 3 % at 2-3 per CU -- DESIGN.md section 6.)"""
 import os
 import sys
 
@@ -25,4 +26,4 @@ for tiles_m, tiles_n in ((16, 16), (32, 16), (48, 16)):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
-    print(f"stages={os.environ.get('WT_GEMM_STAGES', 'default')} tiles={tiles_m * tiles_n} ({tiles_m * tiles_n // 256}/CU) K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+    print(f"tiles={tiles_m * tiles_n} ({tiles_m * tiles_n // 256}/CU) K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")

@@ -132,6 +132,9 @@ def _bench_gemm_f16(M):
         C = torch.empty(M, N, device="cuda", dtype=torch.float16 if oh else torch.float32)
         us = timeit(lambda i: lib.wt_dbg_gemm_f16(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, ST()), 4, iters=3)
         print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+        if not oh and not act:   # as the engine runs out-proj / fc2: fp32 residual stream read and written in place
+            us = timeit(lambda i: lib.wt_dbg_gemm_f16(P(A), K, P(W[i]), P(bias), P(C), P(C), M, N, K, act, oh, ST()), 4, iters=3)
+            print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh} +resid: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
 def bench_gemm_f16_resident(M=24000, N=1024):

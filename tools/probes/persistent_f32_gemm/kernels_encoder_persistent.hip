@@ -1,0 +1,960 @@
+// Encoder-side HIP kernels for gfx950 (MI355X): mel transpose, LayerNorm, fp32 MFMA GEMM with fused
+// bias/GELU/residual/pos-emb epilogues (also used for the two Conv1d as implicit GEMMs and for the
+// cross-attention K/V projection), and a flash-style fp32 MFMA self-attention.
+//
+// Reference semantics: tensorrt_llm/models/whisper/model.py:90-111 (WhisperEncoder.forward),
+// :48-66 (WhisperEncoderLayer), layers/attention.py:216-350; numerics follow the bundled HF oracle
+// modeling_whisper.py:569-593, :632-641, :992-1011 (erf GELU, q scaled before QK^T).
+#include "wt_common.h"
+
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
+
+namespace wt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------------ mel transpose
+// mel [B][C][F] (time contiguous, the layout of run.py's `input_features`) -> melT [B][F+2][C], row = time+1,
+// rows 0 and F+1 are the conv zero padding (written here).  Makes conv1 an implicit GEMM with K = 3*C, lda = C.
+__global__ __launch_bounds__(256) void mel_transpose_kernel(const float* __restrict__ mel, float* __restrict__ melT,
+                                                            int C, int F) {
+    __shared__ float tile[128][65];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        int c = i >> 6, tl = i & 63, t = t0 + tl;
+        tile[c][tl] = t < F ? mel[((size_t)b * C + c) * F + t] : 0.f;
+    }
+    __syncthreads();
+    float* dst = melT + (size_t)b * (F + 2) * C;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        int tl = i / C, c = i - tl * C, t = t0 + tl;
+        if (t < F) dst[(size_t)(t + 1) * C + c] = tile[c][tl];
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < C; i += 256) {
+            dst[i] = 0.f;
+            dst[(size_t)(F + 1) * C + i] = 0.f;
+        }
+}
+
+hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels, int frames, hipStream_t s) {
+    if (n_mels > 128) return hipErrorInvalidValue;
+    dim3 grid((frames + 63) / 64, B);
+    hipLaunchKernelGGL(mel_transpose_kernel, grid, dim3(256), 0, s, mel, melT, n_mels, frames);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, row held in registers (d <= 1280, d % 4 == 0), two-pass mean/variance in fp32, eps 1e-5
+// (layers/normalization.py:10; nn.LayerNorm default).
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                        int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    const int n4 = d >> 2;
+    float4 v[5];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < n4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_allreduce_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        if (c < n4) {
+            float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + bb * bb) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = rsqrtf(wave_allreduce_sum(q) / d + 1e-5f);
+    float4* yr = reinterpret_cast<float4*>(y + (size_t)row * d);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int c = lane + 64 * i;
+        if (c < n4) {
+            float4 g = w4[c], be = b4[c], o;
+            o.x = (v[i].x - mean) * rstd * g.x + be.x;
+            o.y = (v[i].y - mean) * rstd * g.y + be.y;
+            o.z = (v[i].z - mean) * rstd * g.z + be.z;
+            o.w = (v[i].w - mean) * rstd * g.w + be.w;
+            yr[c] = o;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s) {
+    if (d > 1280 || (d & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, d);
+    return hipGetLastError();
+}
+
+// Epilogue shared by the two fp32 GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                              const int wc, const int l31, const int hh) {
+    // Row-dependent addressing (batch split, output row pointer) is computed once per row -- the batch index of the
+    // wave's first row by ONE wave-uniform division, the rest by carry -- and the residual / position rows of a group of
+    // four rows are loaded together before they are used: in a one-round launch nothing overlaps the epilogue, and the
+    // per-element division + load-wait-use chain it replaces cost about a quarter of the K = 1024 launches.
+    int nn[2];
+    float bv[2];
+    bool nok[2];
+    int kv_which[2] = {0, 0}, kv_h[2] = {0, 0}, kv_j[2] = {0, 0};
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+        nok[tj] = nn[tj] < p.N;
+        bv[tj] = (p.bias && nok[tj]) ? p.bias[nn[tj]] : 0.f;
+        if (p.epi == EPI_KV_HEADS) {
+            const int dkv = p.kv_heads * HEAD_DIM;
+            kv_which[tj] = nn[tj] / dkv;
+            const int r2 = nn[tj] - kv_which[tj] * dkv;
+            kv_h[tj] = r2 / HEAD_DIM;
+            kv_j[tj] = r2 - kv_h[tj] * HEAD_DIM;
+        }
+    }
+    const int mw = m0 + wr * 64;                       // first row of this wave (wave-uniform)
+    const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            long long offs[4];
+            int crs[4];
+            bool mok[4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int o = ti * 32 + ri + 8 * rq + 4 * hh;
+                mok[ri] = mw + o < p.M;
+                int cb = cb_w, cr = cr_w + o;
+                while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
+                crs[ri] = cr;
+                offs[ri] = p.epi == EPI_ROWMAJOR ? (long long)cb * p.c_batch_stride + (long long)cr * p.ldc
+                                                 : (long long)cb * p.kv_heads * p.kv_cap * HEAD_DIM + (long long)(cr + p.kv_seq_off) * HEAD_DIM;
+            }
+            float extra[4][2];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    extra[ri][tj] = (p.resid && mok[ri] && nok[tj]) ? p.resid[offs[ri] + nn[tj]] : 0.f;
+            float posv[4][2];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    posv[ri][tj] = (p.pos && mok[ri] && nok[tj]) ? p.pos[(long long)crs[ri] * p.N + nn[tj]] : 0.f;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    if (!(mok[ri] && nok[tj])) continue;
+                    float v = acc[ti][tj][rq * 4 + ri] + bv[tj];
+                    if (p.act) v = gelu_erf(v);
+                    v += posv[ri][tj];
+                    if (p.epi == EPI_ROWMAJOR) {
+                        p.C[offs[ri] + nn[tj]] = v + extra[ri][tj];
+                    } else {
+                        float* base = kv_which[tj] ? p.C2 : p.C;
+                        base[offs[ri] + (long long)kv_h[tj] * p.kv_cap * HEAD_DIM + kv_j[tj]] = v;
+                    }
+                }
+        }
+    }
+}
+
+// Fast epilogue for a wave whose 64x64 sub-tile lies wholly inside C: no bounds masks, the optional operands are compile-time, and the
+// residual / position loads run two row groups ahead of their use in straight-line code, so the only waits are counted vmcnt(N) for
+// loads -- never for the stores.  (gfx9 has ONE counter for loads and stores: in the generic epilogue above every `p.resid ? load : 0`
+// becomes a branch whose join waits vmcnt(0), i.e. for the round trip of all stores issued so far; measured per workgroup, its stores
+// took 13 us to ISSUE alone on a CU and 60 us beside other workgroups' K loops -- a third of a K = 1024 tile's life.)
+template <bool RESID, bool ACT, bool POS, bool KV, bool MASKED = false>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                                   const int wc, const int l31, const int hh) {
+    const int mw = m0 + wr * 64, rpb = p.c_rows_per_batch;
+    const int cb_w = mw / rpb, cr_w = mw - cb_w * rpb;                 // wave-uniform: one division
+    int nn[2], col[2];
+    float bv[2];
+    float* base[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+        if (MASKED) nn[tj] = min(nn[tj], p.N - 1);                      // edge sub-tile: clamp the column, mask the store
+        bv[tj] = p.bias ? p.bias[nn[tj]] : 0.f;
+        if (KV) {
+            const int dkv = p.kv_heads * HEAD_DIM, which = nn[tj] / dkv, r2 = nn[tj] - which * dkv, h = r2 / HEAD_DIM;
+            col[tj] = h * p.kv_cap * HEAD_DIM + (r2 - h * HEAD_DIM);
+            base[tj] = which ? p.C2 : p.C;
+        } else {
+            col[tj] = nn[tj];
+            base[tj] = p.C;
+        }
+    }
+    const int row_stride = KV ? HEAD_DIM : p.ldc;
+    const int batch_stride = KV ? p.kv_heads * p.kv_cap * HEAD_DIM : (int)p.c_batch_stride;
+    const int row_add = KV ? p.kv_seq_off : 0;
+    // group g = (ti, rq): rows o = ti*32 + 8*rq + 4*hh + ri, ri < 4
+    const bool col_ok[2] = {!MASKED || n0 + wc * 64 + l31 < p.N, !MASKED || n0 + wc * 64 + 32 + l31 < p.N};
+    auto row_of = [&](const int g, const int ri, int& cr) -> int {
+        const int o = (g >> 2) * 32 + 8 * (g & 3) + 4 * hh + ri;
+        if (MASKED) {                                                 // edge sub-tile: clamp the row to M-1 (any rpb), mask the store
+            const int m = min(mw + o, p.M - 1), cb = m / rpb;
+            cr = m - cb * rpb;
+            return cb * batch_stride + (cr + row_add) * row_stride;
+        }
+        cr = cr_w + o;
+        const bool over = cr >= rpb;                                  // a 64-row span crosses at most one batch boundary (rpb >= 64)
+        cr -= over ? rpb : 0;
+        return (cb_w + (over ? 1 : 0)) * batch_stride + (cr + row_add) * row_stride;
+    };
+    float rv[2][8], pv[2][8];
+    auto fetch = [&](const int g) {
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            int cr;
+            const int off = row_of(g, ri, cr);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                if (RESID) rv[g & 1][ri * 2 + tj] = p.resid[off + col[tj]];
+                if (POS) pv[g & 1][ri * 2 + tj] = p.pos[cr * p.N + nn[tj]];
+            }
+        }
+    };
+    if (RESID || POS) { fetch(0); fetch(1); }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float v[8];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                float x = acc[g >> 2][tj][(g & 3) * 4 + ri] + bv[tj];
+                if (ACT) x = gelu_erf(x);
+                if (POS) x += pv[g & 1][ri * 2 + tj];
+                if (RESID) x += rv[g & 1][ri * 2 + tj];
+                v[ri * 2 + tj] = x;
+            }
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            int cr;
+            const int off = row_of(g, ri, cr);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                if (MASKED) {
+                    const bool row_ok = mw + (g >> 2) * 32 + 8 * (g & 3) + 4 * hh + ri < p.M;
+                    if (row_ok && col_ok[tj]) base[tj][off + col[tj]] = v[ri * 2 + tj];
+                } else {
+                    base[tj][off + col[tj]] = v[ri * 2 + tj];
+                }
+            }
+        }
+        if ((RESID || POS) && g + 2 < 8) fetch(g + 2);
+    }
+}
+
+// Epilogue kinds with a fast form (the operand combinations the engines use); anything else takes the generic epilogue.
+enum { EK_GENERIC = 0, EK_PLAIN, EK_RESID, EK_ACT, EK_ACT_POS, EK_KV };
+__host__ __device__ inline int gemm_epilogue_kind(const GemmParams& p) {
+    if (!p.epi_fits32) return EK_GENERIC;
+    if (p.epi == EPI_ROWMAJOR && !p.pos) {
+        if (p.resid && !p.act) return EK_RESID;
+        if (!p.resid && p.act) return EK_ACT;
+        if (!p.resid && !p.act) return EK_PLAIN;
+    } else if (p.epi == EPI_ROWMAJOR && p.pos && p.act && !p.resid) {
+        return EK_ACT_POS;
+    } else if (p.epi == EPI_KV_HEADS && !p.pos && !p.act && !p.resid) {
+        return EK_KV;
+    }
+    return EK_GENERIC;
+}
+template <int KIND, bool MASKED>
+__device__ __forceinline__ void gemm_epilogue_kind_call(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                                        const int wc, const int l31, const int hh) {
+    if (KIND == EK_PLAIN) gemm_epilogue_fast<false, false, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
+    else if (KIND == EK_RESID) gemm_epilogue_fast<true, false, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
+    else if (KIND == EK_ACT) gemm_epilogue_fast<false, true, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
+    else if (KIND == EK_ACT_POS) gemm_epilogue_fast<false, true, true, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
+    else if (KIND == EK_KV) gemm_epilogue_fast<false, false, false, true, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
+    else gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+}
+// compile-time kind: interior sub-tiles branch-free, edge sub-tiles the masked form of the same code (rpb >= 64 is only needed inside)
+template <int KIND>
+__device__ __forceinline__ void gemm_epilogue_of_kind(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                                      const int wc, const int l31, const int hh) {
+    if (KIND == EK_GENERIC) return gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+    if (m0 + wr * 64 >= p.M || n0 + wc * 64 >= p.N) return;             // nothing of this sub-tile is inside C
+    const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * 64 + 64 <= p.N && p.c_rows_per_batch >= 64;
+    if (interior) gemm_epilogue_kind_call<KIND, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    else gemm_epilogue_kind_call<KIND, true>(p, acc, m0, n0, wr, wc, l31, hh);
+}
+// run-time kind (one-tile kernels): the fast form for interior sub-tiles, the generic one otherwise
+__device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+                                                  const int wc, const int l31, const int hh) {
+    const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * 64 + 64 <= p.N && p.c_rows_per_batch >= 64;
+    const int kind = interior ? gemm_epilogue_kind(p) : EK_GENERIC;
+    if (kind == EK_RESID) return gemm_epilogue_kind_call<EK_RESID, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    if (kind == EK_ACT) return gemm_epilogue_kind_call<EK_ACT, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    if (kind == EK_PLAIN) return gemm_epilogue_kind_call<EK_PLAIN, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    if (kind == EK_ACT_POS) return gemm_epilogue_kind_call<EK_ACT_POS, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    if (kind == EK_KV) return gemm_epilogue_kind_call<EK_KV, false>(p, acc, m0, n0, wr, wc, l31, hh);
+    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
+// 128x128 block tile, 4 waves in a 2x2 grid, each wave 2x2 tiles of v_mfma_f32_32x32x2_f32 (exact fp32,
+// 64 FLOP/clk/SIMD), K-step 16 (32 selectable).  A and W tiles are staged global -> registers -> LDS (rows padded by 4 floats so the
+// ds_read_b128 fragment reads are bank-conflict free), double-buffered, one barrier per K-step.
+// Fragment trick: one 32x32x2 MFMA takes k = {k0, k1} from lane halves 0/1.  Each lane reads a float4
+// A[row][8q+4h .. +3] and issues 4 MFMAs with element j, so lane half h covers k = 8q+4h+j; A and W use the
+// same k assignment, so the sum over k is complete and no repacking is needed.
+constexpr int GBM = 128, GBN = 128;
+template <int GBK>
+constexpr int gemm_smem_bytes() { return 2 * 2 * GBM * (GBK + 4) * (int)sizeof(float); }  // 73,728 B at BK=32, 40,960 B at BK=16
+
+template <int GBK>
+__global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const GemmParams p) {
+    constexpr int GLD = GBK + 4;
+    constexpr int NC4 = GBK / 4;           // float4 chunks per staged row
+    constexpr int RPP = 256 / NC4;         // rows covered per staging pass
+    constexpr int NPASS = GBM / RPP;       // passes per matrix
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+    // contiguous chunk of the tile list; inside a chunk walk groups of GROUP_M row-tiles column by column so
+    // the co-resident blocks of one XCD reuse a few A row-panels and W column-panels out of its private L2.
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * GBM, n0 = bx * GBN;
+
+    // staging map: 128 rows x NC4 float4; thread -> column c4, rows r0 + RPP*i
+    const int c4 = tid % NC4, r0 = tid / NC4;
+    const float* aptr[NPASS];
+    const float* wptr[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        int m = min(m0 + r0 + RPP * i, p.M - 1);
+        int bb = m / p.a_rows_per_batch;
+        aptr[i] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + c4 * 4;
+        int n = min(n0 + r0 + RPP * i, p.N - 1);
+        wptr[i] = p.W + (long long)n * p.K + c4 * 4;
+    }
+    float4 ra[NPASS], rw[NPASS];
+    auto gload = [&](int kt) {
+        const int k = kt * GBK + c4 * 4;
+        const bool ok = k < p.K;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            ra[i] = ok ? *reinterpret_cast<const float4*>(aptr[i] + kt * GBK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = ok ? *reinterpret_cast<const float4*>(wptr[i] + kt * GBK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * (2 * GBM * GLD);
+        float* Ws = As + GBM * GLD;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            *reinterpret_cast<float4*>(As + (r0 + RPP * i) * GLD + c4 * 4) = ra[i];
+            *reinterpret_cast<float4*>(Ws + (r0 + RPP * i) * GLD + c4 * 4) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + GBK - 1) / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* As = smem + cur * (2 * GBM * GLD) + (wr * 64 + l31) * GLD + 4 * hh;
+        const float* Ws = smem + cur * (2 * GBM * GLD) + GBM * GLD + (wc * 64 + l31) * GLD + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < GBK / 8; ++q) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + 8 * q);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + 32 * GLD + 8 * q);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + 8 * q);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + 32 * GLD + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    gemm_epilogue_any(p, acc, m0, n0, wr, wc, l31, hh);
+}
+
+// The same GEMM with the tiles staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPR staging, no ds_write),
+// used when K is a multiple of 16.  One wave instruction writes 1 KiB linearly (wave-uniform base + lane * 16 B), so the LDS
+// tile is UNPADDED, [row][4 chunks of 4 floats], and bank conflicts of the fragment reads are avoided by an XOR swizzle
+// applied on both sides (cdna guide §5.4 rule 21): the lane that fills LDS chunk position `pos` of row r fetches global
+// chunk pos ^ ((r >> 2) & 3); a fragment read of chunk c of row r reads position c ^ ((r >> 2) & 3).  Rows 4a+b, a,b < 4,
+// then cover all 16 sixteen-byte bank groups for every c.  Three 16 KiB stages (48 KiB -> three workgroups per CU; four waves per
+// SIMD sustain LESS MFMA throughput than three, tools/probes/mfma_rate.hip: 125 vs 155 TFLOP/s of pure v_mfma_f32_32x32x2_f32):
+// the DMA of tile kt+2 is issued right after the barrier that opens tile kt, and the wait at the top of a step is counted
+// (vmcnt(4): tile kt+1's four DMA instructions may still be in flight).
+template <bool STAMP>
+__global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p) {
+    constexpr int STAGES = 3;
+    constexpr int BK = 16;
+    long long t_start = 0, t_first = 0, t_loop = 0;   // probe build: wall-clock stamps (100 MHz)
+    if (STAMP) t_start = wall_clock64();
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware tile order (see gemm_f32_kernel)
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * GBM, n0 = bx * GBN;
+
+    // DMA map: wave w, pass j fills rows j*64 + w*16 .. +15; lane -> (row lane >> 2, chunk position lane & 3)
+    const int r_local = lane >> 2, csrc = (lane & 3) ^ ((r_local >> 2) & 3);
+    const float* aptr[2];
+    const float* wptr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = j * 64 + wave * 16 + r_local;
+        const int m = min(m0 + row, p.M - 1);
+        const int bb = m / p.a_rows_per_batch;
+        aptr[j] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 4;
+        const int n = min(n0 + row, p.N - 1);
+        wptr[j] = p.W + (long long)n * p.K + csrc * 4;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const int stage, const int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+        }
+    };
+
+    // fragment reads: rows wr*64 + l31 (+32) of A, wc*64 + l31 (+32) of W; chunk 2q + hh at position (2q + hh) ^ swz
+    const int swz = (l31 >> 2) & 3;
+    const int ra = (wr * 64 + l31) * BK, rb = (wc * 64 + l31) * BK;
+    const int po0 = ((0 + hh) ^ swz) * 4, po1 = ((2 + hh) ^ swz) * 4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    const int nk = p.K / BK;
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's share of tile kt has landed (with three stages tile kt+1's four DMA instructions may still be in flight)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... everyone's has, and nobody still reads the stage refilled next (the fragment reads of step kt-1 were waited for
+        // before its MFMAs).  A raw s_barrier: __syncthreads() would add a vmcnt(0) fence and undo the counted wait.
+        __builtin_amdgcn_s_barrier();
+        if (STAMP && kt == 0) t_first = wall_clock64();
+        const float* As = &smem[cur][0][0];
+        const float* Ws = &smem[cur][1][0];
+        const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
+        const int fill = cur == 0 ? STAGES - 1 : cur - 1;                          // the stage read during step kt-1
+        // (pinning all eight fragment reads above the first MFMA with sched_barrier measured 7 % SLOWER: the compiler's own
+        //  interleaving of the second four reads with the first sixteen MFMAs is the better schedule)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int po = q ? po1 : po0;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ra + po);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
+            if (q == 0 && kt + STAGES - 1 < nk) dma(fill, kt + STAGES - 1);  // after the first fragment reads are on their way
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
+            }
+        }
+        cur = nxt;
+    }
+    if (STAMP) t_loop = wall_clock64();
+    gemm_epilogue_any(p, acc, m0, n0, wr, wc, l31, hh);
+    if (STAMP) {
+        const long long t_issued = wall_clock64();           // every store of this wave issued (the product kernel ends here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            long long* o = p.dbg_stamps + (long long)blockIdx.x * 8;
+            o[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));   // HW_REG_HW_ID
+            o[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID
+            o[2] = t_start; o[3] = t_first; o[4] = t_loop; o[5] = wall_clock64(); o[6] = t_issued; o[7] = 0;
+        }
+    }
+}
+
+// PERSISTENT form of the kernel above for launches of more than one round of tiles (> 768 = 3 workgroups x 256 CUs): 768 workgroups,
+// each a continuous stream of K-steps over the tiles it draws from its XCD's share of the (XCD-chunked) tile list.  What it removes,
+// measured with the probe build on M = 12000, N = 4096, K = 1024 (per workgroup of the one-tile kernel: 9 us until the first tile
+// lands -- its first DMA queues behind the previous tenant's stores in the CU's in-order vector-memory path -- 167 us of K loop,
+// 8 us of epilogue): the first two K-steps of tile t+1 are requested during the last two K-steps of tile t, i.e. AHEAD of tile t's
+// stores, and land under its epilogue.  Tiles are drawn DYNAMICALLY (one device-scope atomic per tile on tickets[xcd], requested a
+// whole tile before it is needed): the oldest workgroup of a CU gets MFMA issue priority and finishes ~1.35x faster than the
+// youngest, so a static split would leave the youngest alone at the end.  tickets[0..8] are zero between launches: every workgroup
+// draws until it gets a ticket past its XCD's share, and the last workgroup to leave (tickets[8]) zeroes them.
+template <int KIND>
+__global__ __launch_bounds__(256, 3) void gemm_f32_dma_persistent_kernel(const GemmParams p, int* __restrict__ tickets) {
+    constexpr int BK = 16;
+    __shared__ __attribute__((aligned(1024))) float smem[3][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
+    __shared__ int s_ticket[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
+    const int xcd = blockIdx.x & 7;
+    const int x_count = (total >> 3) + (xcd < (total & 7) ? 1 : 0);
+    const int x_start = xcd < (total & 7) ? xcd * ((total >> 3) + 1) : (total & 7) * ((total >> 3) + 1) + (xcd - (total & 7)) * (total >> 3);
+
+    // DMA map and fragment reads as in gemm_f32_dma_kernel
+    const int r_local = lane >> 2, csrc = (lane & 3) ^ ((r_local >> 2) & 3);
+    const int swz = (l31 >> 2) & 3;
+    const int ra = (wr * 64 + l31) * BK, rb = (wc * 64 + l31) * BK;
+    const int po0 = ((0 + hh) ^ swz) * 4, po1 = ((2 + hh) ^ swz) * 4;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    struct TilePtrs { const float* a[2]; const float* w[2]; };
+    auto tile_ptrs = [&](const int ticket, TilePtrs& t, int& m0, int& n0) {
+        constexpr int GROUP_M = 8;
+        const int bid = x_start + ticket, per_group = GROUP_M * nbx, g = bid / per_group;
+        const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+        m0 = (g * GROUP_M + in_g % gm) * GBM;
+        n0 = (in_g / gm) * GBN;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = j * 64 + wave * 16 + r_local;
+            const int m = min(m0 + row, p.M - 1);
+            const int bb = m / p.a_rows_per_batch;
+            t.a[j] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 4;
+            t.w[j] = p.W + (long long)min(n0 + row, p.N - 1) * p.K + csrc * 4;
+        }
+    };
+    auto dma = [&](const int stage, const TilePtrs& t, const int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(t.a[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(t.w[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+        }
+    };
+
+    // first ticket (waited for), second ticket (in flight until step 0 of the first tile)
+    int drawn = 0;                                     // thread 0 only: the ticket requested for the tile after the current one
+    if (tid == 0) {
+        s_ticket[0] = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]);   // wave-uniform by construction: keep the tile arithmetic on the scalar unit
+    __syncthreads();
+    if (ticket < x_count && tid == 0) drawn = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    const int nk = p.K / BK;                           // >= 3 (launch_gemm_f32)
+    TilePtrs cur_t, nxt_t;
+    int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
+    bool have_next = false;
+    int cur = 0, skip = 0;
+    if (ticket < x_count) {
+        tile_ptrs(ticket, cur_t, m0, n0);
+        dma(0, cur_t, 0);
+        dma(1, cur_t, 1);
+    }
+    while (ticket < x_count) {                         // block-uniform
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+        int next_ticket = x_count;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt == 0 && tid == 0) s_ticket[1] = drawn;            // resolved a whole tile (or the prologue) after it was requested
+            if (skip > 0) --skip;                                     // landed before the previous epilogue's stores were issued
+            else if (kt + 1 < nk || have_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the s_ticket store above (and nothing else) is done
+            __builtin_amdgcn_s_barrier();
+            if (kt == 0) {
+                next_ticket = __builtin_amdgcn_readfirstlane(s_ticket[1]);
+                have_next = next_ticket < x_count;
+                if (have_next) {
+                    tile_ptrs(next_ticket, nxt_t, m0n, n0n);
+                    if (tid == 0) drawn = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const float* As = &smem[cur][0][0];
+            const float* Ws = &smem[cur][1][0];
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const int fill = cur == 0 ? 2 : cur - 1;                 // the stage read during the previous step
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int po = q ? po1 : po0;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ra + po);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
+                if (q == 0) {
+                    if (kt + 2 < nk) dma(fill, cur_t, kt + 2);
+                    else if (have_next) dma(fill, nxt_t, kt + 2 - nk);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
+                }
+            }
+            cur = nxt;
+        }
+        // The next tile's first two K-steps were requested during the last two steps above: let them land BEFORE this tile's stores
+        // are issued (one counter for loads and stores: a counted wait behind 64 stores would wait for the stores' round trips).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        skip = have_next ? 2 : 0;
+        gemm_epilogue_of_kind<KIND>(p, acc, m0, n0, wr, wc, l31, hh);
+        ticket = next_ticket;
+        cur_t = nxt_t;
+        m0 = m0n;
+        n0 = n0n;
+        have_next = false;
+    }
+    if (tid == 0) {
+        const int gone = __hip_atomic_fetch_add(&tickets[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(&tickets[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Ticket counters of the persistent kernel: nine ints per (device, stream), zero between launches (the kernel leaves them zero).
+// Launches on one stream are ordered, so they can share a set; allocated on first use -- never while the stream is being captured
+// into a graph (then, or if the allocation fails, the one-tile kernel is used).
+static int* gemm_tickets_for(hipStream_t s) {
+    struct Entry { int device; hipStream_t stream; int* ptr; };
+    static std::mutex mu;
+    static std::vector<Entry> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : table)
+        if (e.device == dev && e.stream == s) return e.ptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    int* ptr = nullptr;
+    if (hipMalloc((void**)&ptr, 16 * sizeof(int)) != hipSuccess || hipMemset(ptr, 0, 16 * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ptr) (void)hipFree(ptr);
+        return nullptr;
+    }
+    table.push_back(Entry{dev, s, ptr});
+    return ptr;
+}
+
+hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    {
+        // the fast epilogue indexes C / resid / pos with 32-bit element offsets
+        const long long batches = (p.M + (long long)p.c_rows_per_batch - 1) / (p.c_rows_per_batch > 0 ? p.c_rows_per_batch : 1) + 1;
+        const long long reach = p.epi == EPI_KV_HEADS
+                                    ? batches * p.kv_heads * p.kv_cap * HEAD_DIM + ((long long)p.c_rows_per_batch + p.kv_seq_off) * HEAD_DIM
+                                    : batches * (p.c_batch_stride > 0 ? p.c_batch_stride : 0) + ((long long)p.c_rows_per_batch + 1) * p.ldc + p.N;
+        const long long pos_reach = ((long long)p.c_rows_per_batch + 1) * p.N;
+        p.epi_fits32 = reach < (1ll << 31) && pos_reach < (1ll << 31) && p.c_batch_stride >= 0 && p.ldc >= 0;
+    }
+    if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3) || p.c_rows_per_batch < 1 || p.a_rows_per_batch < 1) return hipErrorInvalidValue;
+    static PerDeviceFlag attr_set;
+    static int force_bk = 0;
+    if (!attr_set.get()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<32>());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<16>());
+        if (e != hipSuccess) return e;
+        const char* ev = getenv("WT_GEMM_BK");
+        force_bk = ev ? atoi(ev) : 0;
+        attr_set.set();
+    }
+    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM;
+    // measured (tools/microbench.py gemm, M=12000): BK=16 (41 KB of LDS, 128 VGPRs -> 3-4 resident blocks per CU, smaller idle
+    // tail in the last round of tiles) beats BK=32 (2 blocks per CU) on every encoder shape: 97-120 vs 77-108 TFLOP/s
+    const int tiles = nbx * nby;
+    int bk = 16;
+    if (force_bk == 16 || force_bk == 32) bk = force_bk;
+    static const bool no_dma = getenv("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
+    if (!no_dma && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
+    {
+        // more than one round of tiles: the persistent kernel (A/B switch WT_GEMM_NO_PERSISTENT=1)
+        static const bool no_persistent = getenv("WT_GEMM_NO_PERSISTENT") != nullptr;
+        constexpr int PERSISTENT_GRID = 768;   // 3 workgroups (48 KiB of LDS each) x 256 CUs; a multiple of 8: a workgroup keeps its XCD
+        int* tickets = nullptr;
+        const int kind = gemm_epilogue_kind(p);
+        if (!no_persistent && !p.dbg_stamps && tiles > PERSISTENT_GRID && p.K >= 3 * 16 && kind != EK_GENERIC) tickets = gemm_tickets_for(s);
+        if (tickets && kind == EK_PLAIN) hipLaunchKernelGGL(gemm_f32_dma_persistent_kernel<EK_PLAIN>, dim3(PERSISTENT_GRID), dim3(256), 0, s, p, tickets);
+        else if (tickets && kind == EK_RESID) hipLaunchKernelGGL(gemm_f32_dma_persistent_kernel<EK_RESID>, dim3(PERSISTENT_GRID), dim3(256), 0, s, p, tickets);
+        else if (tickets && kind == EK_ACT) hipLaunchKernelGGL(gemm_f32_dma_persistent_kernel<EK_ACT>, dim3(PERSISTENT_GRID), dim3(256), 0, s, p, tickets);
+        else if (tickets && kind == EK_ACT_POS) hipLaunchKernelGGL(gemm_f32_dma_persistent_kernel<EK_ACT_POS>, dim3(PERSISTENT_GRID), dim3(256), 0, s, p, tickets);
+        else if (tickets && kind == EK_KV) hipLaunchKernelGGL(gemm_f32_dma_persistent_kernel<EK_KV>, dim3(PERSISTENT_GRID), dim3(256), 0, s, p, tickets);
+        else if (p.dbg_stamps) hipLaunchKernelGGL(gemm_f32_dma_kernel<true>, dim3(tiles), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemm_f32_dma_kernel<false>, dim3(tiles), dim3(256), 0, s, p);
+    }
+    else if (bk == 16) hipLaunchKernelGGL(gemm_f32_kernel<16>, dim3(tiles), dim3(256), gemm_smem_bytes<16>(), s, p);
+    else hipLaunchKernelGGL(gemm_f32_kernel<32>, dim3(tiles), dim3(256), gemm_smem_bytes<32>(), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ encoder attention
+// softmax(Q K^T / 8) V per (utterance, head), S = 1500 keys, head_dim 64, no mask (layers/attention.py:308,
+// 337-345; HF :569-593).  Flash-style: scores never leave registers.  One workgroup = 128 queries (4 waves x 32),
+// K/V tiles of 64 keys double-buffered in LDS.  Both products run on v_mfma_f32_32x32x2_f32 with the
+// TRANSPOSED orientation so that the query index sits on the lane:
+//   S^T[key][query] = K . Q^T     -> lane (query, half h) holds 16 keys per 32-key tile
+//   O^T[dv][query] += V^T . P^T   -> P comes straight from the S^T accumulator registers (same lane,
+//                                    same k assignment), the row max / sum / rescale are lane-local.
+constexpr int FA_BQ = 128, FA_BKV = 64, FA_LD = 68;
+constexpr int FA_SMEM = 2 * 2 * FA_BKV * FA_LD * (int)sizeof(float);  // 69,632 B
+
+__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
+                                                          int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * FA_BQ;
+    const int d = H * HEAD_DIM, ld = 3 * d;
+    const float* base = qkv + (size_t)b * S * ld + h * HEAD_DIM;
+
+    // Q fragment (B operand of S^T): lane (query, h) holds Q[query][8q+4h .. +3], pre-scaled by 64^-0.5 (exact)
+    const int qrow = q0 + wave * 32 + l31;
+    f32x4 qf[8];
+    {
+        const float* qp = base + (size_t)min(qrow, S - 1) * ld + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            qf[q] = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+            qf[q] *= 0.125f;
+        }
+    }
+    // staging map: 64 keys x 16 float4 per matrix; thread -> column c4, rows r0 + 16*i
+    const int c4 = tid & 15, r0 = tid >> 4;
+    // staging registers as named vectors (an array here is left in scratch by hipcc: 1.2 GB of spill traffic per launch)
+    f32x4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    const float* gbase = base + c4 * 4;
+#define FA_GLOAD(kv0_)                                                                   \
+    do {                                                                                 \
+        const float* rp0 = gbase + (size_t)min((kv0_) + r0, S - 1) * ld;                 \
+        const float* rp1 = gbase + (size_t)min((kv0_) + r0 + 16, S - 1) * ld;            \
+        const float* rp2 = gbase + (size_t)min((kv0_) + r0 + 32, S - 1) * ld;            \
+        const float* rp3 = gbase + (size_t)min((kv0_) + r0 + 48, S - 1) * ld;            \
+        rk0 = *reinterpret_cast<const f32x4*>(rp0 + d); rv0 = *reinterpret_cast<const f32x4*>(rp0 + 2 * d); \
+        rk1 = *reinterpret_cast<const f32x4*>(rp1 + d); rv1 = *reinterpret_cast<const f32x4*>(rp1 + 2 * d); \
+        rk2 = *reinterpret_cast<const f32x4*>(rp2 + d); rv2 = *reinterpret_cast<const f32x4*>(rp2 + 2 * d); \
+        rk3 = *reinterpret_cast<const f32x4*>(rp3 + d); rv3 = *reinterpret_cast<const f32x4*>(rp3 + 2 * d); \
+    } while (0)
+#define FA_LSTORE(buf_)                                                                  \
+    do {                                                                                 \
+        float* Ks_ = smem + (buf_) * (2 * FA_BKV * FA_LD) + r0 * FA_LD + c4 * 4;         \
+        float* Vs_ = Ks_ + FA_BKV * FA_LD;                                               \
+        *reinterpret_cast<f32x4*>(Ks_) = rk0; *reinterpret_cast<f32x4*>(Vs_) = rv0;      \
+        *reinterpret_cast<f32x4*>(Ks_ + 16 * FA_LD) = rk1; *reinterpret_cast<f32x4*>(Vs_ + 16 * FA_LD) = rv1; \
+        *reinterpret_cast<f32x4*>(Ks_ + 32 * FA_LD) = rk2; *reinterpret_cast<f32x4*>(Vs_ + 32 * FA_LD) = rv2; \
+        *reinterpret_cast<f32x4*>(Ks_ + 48 * FA_LD) = rk3; *reinterpret_cast<f32x4*>(Vs_ + 48 * FA_LD) = rv3; \
+    } while (0)
+
+    // named accumulators (not arrays of vectors: a runtime-looking index sends those to scratch, cdna guide rule 20)
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (S + FA_BKV - 1) / FA_BKV;
+    FA_GLOAD(0);
+    FA_LSTORE(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, kv0 = t * FA_BKV;
+        if (t + 1 < ntiles) FA_GLOAD(kv0 + FA_BKV);
+        const float* Ks = smem + cur * (2 * FA_BKV * FA_LD);
+        const float* Vs = Ks + FA_BKV * FA_LD;
+
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+        const float* kp = Ks + l31 * FA_LD + 4 * hh;
+        // K fragments are read one 8-wide k-group ahead of the MFMAs that use them
+        f32x4 kf0[8], kf1[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            kf0[q] = *reinterpret_cast<const f32x4*>(kp + 8 * q);
+            kf1[q] = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q + 2 < 8) {
+                kf0[q + 2] = *reinterpret_cast<const f32x4*>(kp + 8 * (q + 2));
+                kf1[q + 2] = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * (q + 2));
+            }
+            const f32x4 k0 = kf0[q], k1 = kf1[q], qq = qf[q];
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[0], qq[0], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[0], qq[0], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[1], qq[1], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[1], qq[1], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[2], qq[2], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[2], qq[2], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[3], qq[3], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[3], qq[3], s1, 0, 0, 0);
+        }
+        if (kv0 + FA_BKV > S) {  // ragged last tile: keys >= S get probability 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __expf(s0[r] - m_new);
+            s1[r] = __expf(s1[r] - m_new);
+            ps += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + ps;  // per-lane partial (16 of the query's 32 keys per tile); halves merged at the end
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        const float* vbase = Vs + 4 * hh * FA_LD + l31;
+        // P.V: V values are fetched four keys ahead of the MFMAs that consume them (counted LDS waits, no per-MFMA stall)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = vbase[(8 * g + i) * FA_LD];
+                vb[i] = vbase[(8 * g + i) * FA_LD + 32];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], s0[4 * g + i], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[i], s0[4 * g + i], o1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = vbase[(32 + 8 * g + i) * FA_LD];
+                vb[i] = vbase[(32 + 8 * g + i) * FA_LD + 32];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], s1[4 * g + i], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[i], s1[4 * g + i], o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) FA_LSTORE(cur ^ 1);
+        __syncthreads();
+    }
+#undef FA_GLOAD
+#undef FA_LSTORE
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (qrow < S) {
+        float* op = ctx + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(op + 8 * g) =
+                make_float4(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                make_float4(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s) {
+    static PerDeviceFlag attr_set;
+    if (!attr_set.get()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
+        if (e != hipSuccess) return e;
+        attr_set.set();
+    }
+    dim3 grid((S + FA_BQ - 1) / FA_BQ, H, B);
+    hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(256), FA_SMEM, s, qkv, ctx, S, H);
+    return hipGetLastError();
+}
+
+}  // namespace wt
