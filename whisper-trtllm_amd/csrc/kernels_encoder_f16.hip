@@ -509,6 +509,93 @@ __device__ __forceinline__ void hgemm_epilogue_lds8(const GemmParams& p, const f
     }
 }
 
+// Branch-free form of hgemm_epilogue_lds8 for a wave whose 64x64 sub-tile lies wholly inside C with 16-byte-aligned rows: the optional
+// operands are compile-time (KIND), the residual / position rows are requested two passes ahead of their use, and nothing in it is a
+// branch -- so hipcc's waitcnt pass emits counted waits for those loads only.  In the generic form every `if (p.resid)` / `continue`
+// joins with `s_waitcnt vmcnt(0)`: a round trip of every store issued so far AND of the next tile's LDS-DMA in flight, 16 times a tile.
+enum { HEK_PLAIN = 0, HEK_RESID = 1, HEK_ACT = 2, HEK_ACT_POS = 3 };
+template <bool OUT_HALF, int KIND>
+__device__ __forceinline__ void hgemm_epilogue_lds8_fast(const GemmParams& p, const f32x4 (&acc)[4][4], const int m0, const int n0, const int wr,
+                                                         const int wc, const int lane, float* __restrict__ ew) {
+    constexpr bool RESID = KIND == HEK_RESID, ACT = KIND == HEK_ACT || KIND == HEK_ACT_POS, POS = KIND == HEK_ACT_POS;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int lr = lane >> 3, c = lane & 7;
+    const int rswz = (((lr >> 1) & 1) << 4) ^ ((lr & 1) << 2);
+    const int nn[2] = {n0 + wc * 64 + 4 * c, n0 + wc * 64 + 32 + 4 * c};
+    float4 bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bv[h] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nn[h]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int mw = m0 + wr * 64, rpb = p.c_rows_per_batch;
+    const int cb_w = mw / rpb, cr_w = mw - cb_w * rpb;
+    auto row_of = [&](const int pass, int& cr) -> long long {        // pass = ti * 2 + rb / 2
+        const int o = (pass >> 1) * 16 + (lr >> 1) * 4 + (pass & 1) * 2 + (lr & 1);
+        cr = cr_w + o;
+        const bool over = cr >= rpb;                                  // rpb >= 64: at most one batch boundary inside the sub-tile
+        cr -= over ? rpb : 0;
+        return (long long)(cb_w + (over ? 1 : 0)) * p.c_batch_stride + (long long)cr * p.ldc;
+    };
+    float4 rq[2][2], pq[2][2];
+    auto fetch = [&](const int pass) {
+        int cr;
+        const long long rowoff = row_of(pass, cr);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (RESID) rq[pass & 1][h] = *reinterpret_cast<const float4*>(p.resid + rowoff + nn[h]);
+            if (POS) pq[pass & 1][h] = *reinterpret_cast<const float4*>(p.pos + (long long)cr * p.N + nn[h]);
+        }
+    };
+    if (RESID || POS) { fetch(0); fetch(1); }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int ti = pass >> 1, rb = (pass & 1) * 2;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+                ew[(kq * 2 + rr) * 64 + ((tj * 16 + l15) ^ ((kq & 1) << 4) ^ (rr << 2))] = acc[ti][tj][rb + rr];
+        float4 a[2];
+        a[0] = *reinterpret_cast<const float4*>(&ew[lr * 64 + ((4 * c) ^ rswz)]);
+        a[1] = *reinterpret_cast<const float4*>(&ew[lr * 64 + ((32 + 4 * c) ^ rswz)]);
+        int cr;
+        const long long rowoff = row_of(pass, cr);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[4] = {a[h].x + bv[h].x, a[h].y + bv[h].y, a[h].z + bv[h].z, a[h].w + bv[h].w};
+            if (ACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_h(v[e]);
+            }
+            if (POS) { v[0] += pq[pass & 1][h].x; v[1] += pq[pass & 1][h].y; v[2] += pq[pass & 1][h].z; v[3] += pq[pass & 1][h].w; }
+            if (RESID) { v[0] += rq[pass & 1][h].x; v[1] += rq[pass & 1][h].y; v[2] += rq[pass & 1][h].z; v[3] += rq[pass & 1][h].w; }
+            if (OUT_HALF) {
+                __half2* dst = reinterpret_cast<__half2*>(reinterpret_cast<__half*>(p.C) + rowoff + nn[h]);
+                dst[0] = __floats2half2_rn(v[0], v[1]);
+                dst[1] = __floats2half2_rn(v[2], v[3]);
+            } else {
+                *reinterpret_cast<float4*>(p.C + rowoff + nn[h]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if ((RESID || POS) && pass + 2 < 8) fetch(pass + 2);
+    }
+}
+// dispatch: the fast form for interior, aligned sub-tiles of the operand combinations the engine uses, the generic one otherwise
+template <bool OUT_HALF>
+__device__ __forceinline__ void hgemm_epilogue_lds8_any(const GemmParams& p, const f32x4 (&acc)[4][4], const int m0, const int n0, const int wr,
+                                                        const int wc, const int lane, float* __restrict__ ew) {
+    const bool fast = m0 + wr * 64 + 64 <= p.M && n0 + wc * 64 + 64 <= p.N && p.c_rows_per_batch >= 64 && ((p.ldc & 3) == 0) &&
+                      ((p.c_batch_stride & 3) == 0) && ((p.N & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.resid) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.pos) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    if (fast && !p.pos) {
+        if (!p.resid && !p.act) return hgemm_epilogue_lds8_fast<OUT_HALF, HEK_PLAIN>(p, acc, m0, n0, wr, wc, lane, ew);
+        if (p.resid && !p.act) return hgemm_epilogue_lds8_fast<OUT_HALF, HEK_RESID>(p, acc, m0, n0, wr, wc, lane, ew);
+        if (!p.resid && p.act) return hgemm_epilogue_lds8_fast<OUT_HALF, HEK_ACT>(p, acc, m0, n0, wr, wc, lane, ew);
+    } else if (fast && p.act && !p.resid) {
+        return hgemm_epilogue_lds8_fast<OUT_HALF, HEK_ACT_POS>(p, acc, m0, n0, wr, wc, lane, ew);
+    }
+    hgemm_epilogue_lds8<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, ew);
+}
+
 // PERSISTENT 256x128x64 kernel for the big-batch GEMMs: 8 waves (4 x 2, 64x64 per wave), THREE 48 KiB stages + 16 KiB of epilogue
 // scratch = the whole 160 KiB LDS, one workgroup per CU looping over its tiles (t = blockIdx, blockIdx + grid, ...: a block keeps
 // its XCD label, so the XCD-chunked tile order survives).
@@ -631,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
     };
     frag(fa0, fb0, 0, po0);
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): both edges into the loop header carry an empty LDS scoreboard (see the loop's end)
-    int cur = 0, kt = 0, c_i = 0, m0, n0;
+    int cur = 0, kt = 0, c_i = 0, m0, n0, skip = 0;
     tile_origin(0, m0, n0);
     for (int g = 0; g < steps; ++g) {
         const int nxt = cur == 2 ? 0 : cur + 1;
@@ -641,7 +728,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my reads of stage `cur` are done (16 MFMAs were queued behind them)
         if (g + 1 < steps) {
-            if (g + 2 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step g+1 landed (step g+2 may fly)
+            if (skip) skip = 0;                                                      // waited for before the last epilogue's stores
+            else if (g + 2 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // step g+1 landed (step g+2 may fly)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -657,7 +745,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) alone
         cur = nxt;
         if (++kt == nk) {   // this tile's K is complete: finish it under the flight of the next tile's first K-steps
-            hgemm_epilogue_lds8<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, ew);
+            // Step g+2 would be waited for in the middle of the next step, i.e. BEHIND this epilogue's stores in the one in-order
+            // counter: take that wait now (step g+3 may stay in flight) and skip it there.
+            if (g + 3 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            skip = 1;
+            hgemm_epilogue_lds8_any<OUT_HALF>(p, acc, m0, n0, wr, wc, lane, ew);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
