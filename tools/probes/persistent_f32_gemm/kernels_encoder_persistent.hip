@@ -189,7 +189,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
 // took 13 us to ISSUE alone on a CU and 60 us beside other workgroups' K loops -- a third of a K = 1024 tile's life.)
 template <bool RESID, bool ACT, bool POS, bool KV, bool MASKED = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
-                                                   const int wc, const int l31, const int hh) {
+                                                   const int wc, const int l31, const int hh, const float* bias_pre = nullptr) {
     const int mw = m0 + wr * 64, rpb = p.c_rows_per_batch;
     const int cb_w = mw / rpb, cr_w = mw - cb_w * rpb;                 // wave-uniform: one division
     int nn[2], col[2];
@@ -199,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
     for (int tj = 0; tj < 2; ++tj) {
         nn[tj] = n0 + wc * 64 + tj * 32 + l31;
         if (MASKED) nn[tj] = min(nn[tj], p.N - 1);                      // edge sub-tile: clamp the column, mask the store
-        bv[tj] = p.bias ? p.bias[nn[tj]] : 0.f;
+        bv[tj] = bias_pre ? bias_pre[tj] : (p.bias ? p.bias[nn[tj]] : 0.f);   // (bias_pre: a compile-time-known array of the caller)
         if (KV) {
             const int dkv = p.kv_heads * HEAD_DIM, which = nn[tj] / dkv, r2 = nn[tj] - which * dkv, h = r2 / HEAD_DIM;
             col[tj] = h * p.kv_cap * HEAD_DIM + (r2 - h * HEAD_DIM);
@@ -288,23 +288,23 @@ __host__ __device__ inline int gemm_epilogue_kind(const GemmParams& p) {
 }
 template <int KIND, bool MASKED>
 __device__ __forceinline__ void gemm_epilogue_kind_call(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
-                                                        const int wc, const int l31, const int hh) {
-    if (KIND == EK_PLAIN) gemm_epilogue_fast<false, false, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
-    else if (KIND == EK_RESID) gemm_epilogue_fast<true, false, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
-    else if (KIND == EK_ACT) gemm_epilogue_fast<false, true, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
-    else if (KIND == EK_ACT_POS) gemm_epilogue_fast<false, true, true, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
-    else if (KIND == EK_KV) gemm_epilogue_fast<false, false, false, true, MASKED>(p, acc, m0, n0, wr, wc, l31, hh);
+                                                        const int wc, const int l31, const int hh, const float* bias_pre = nullptr) {
+    if (KIND == EK_PLAIN) gemm_epilogue_fast<false, false, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
+    else if (KIND == EK_RESID) gemm_epilogue_fast<true, false, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
+    else if (KIND == EK_ACT) gemm_epilogue_fast<false, true, false, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
+    else if (KIND == EK_ACT_POS) gemm_epilogue_fast<false, true, true, false, MASKED>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
+    else if (KIND == EK_KV) gemm_epilogue_fast<false, false, false, true, MASKED>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
     else gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
 }
 // compile-time kind: interior sub-tiles branch-free, edge sub-tiles the masked form of the same code (rpb >= 64 is only needed inside)
 template <int KIND>
 __device__ __forceinline__ void gemm_epilogue_of_kind(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
-                                                      const int wc, const int l31, const int hh) {
+                                                      const int wc, const int l31, const int hh, const float* bias_pre) {
     if (KIND == EK_GENERIC) return gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
     if (m0 + wr * 64 >= p.M || n0 + wc * 64 >= p.N) return;             // nothing of this sub-tile is inside C
     const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * 64 + 64 <= p.N && p.c_rows_per_batch >= 64;
-    if (interior) gemm_epilogue_kind_call<KIND, false>(p, acc, m0, n0, wr, wc, l31, hh);
-    else gemm_epilogue_kind_call<KIND, true>(p, acc, m0, n0, wr, wc, l31, hh);
+    if (interior) gemm_epilogue_kind_call<KIND, false>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
+    else gemm_epilogue_kind_call<KIND, true>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
 }
 // run-time kind (one-tile kernels): the fast form for interior sub-tiles, the generic one otherwise
 __device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
@@ -599,20 +599,30 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_persistent_kernel(const G
         }
     };
 
-    // first ticket (waited for), second ticket (in flight until step 0 of the first tile)
-    int drawn = 0;                                     // thread 0 only: the ticket requested for the tile after the current one
+    const unsigned smem_base = (unsigned)(unsigned long long)(lptr_t)(&smem[0][0][0]);          // LDS byte address of stage 0
+    const unsigned off_a0 = (ra + po0) * 4, off_b0 = GBM * BK * 4 + (rb + po0) * 4;           // per-lane fragment addresses inside a stage
+    const unsigned off_a1 = (ra + po1) * 4, off_b1 = GBM * BK * 4 + (rb + po1) * 4;
+    // Tickets run TWO tiles ahead so that no result of a vector-memory operation is consumed inside the K loop (hipcc's waitcnt pass
+    // guards such a use with vmcnt(0) -- a drain of the LDS-DMA in flight -- in every wave, used or not): the tickets of this
+    // workgroup's first two tiles are drawn and waited for here; after that, behind the vmcnt(0) every wave takes before a tile's
+    // epilogue anyway, thread 0 publishes the ticket of tile t+2 (requested one tile earlier) through LDS and requests tile t+3's.
+    // Tickets of one XCD are monotonic, so the first invalid one (>= x_count) ends a workgroup's chain: it draws exactly one.
+    int drawn = x_count;                               // thread 0 only: the newest requested ticket
     if (tid == 0) {
-        s_ticket[0] = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t0 = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t1 = t0 < x_count ? __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : x_count;
+        s_ticket[0] = t0;
+        s_ticket[1] = t1;
     }
     __syncthreads();
-    int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]);   // wave-uniform by construction: keep the tile arithmetic on the scalar unit
+    int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]);       // wave-uniform by construction: tile arithmetic on the scalar unit
+    int next_ticket = __builtin_amdgcn_readfirstlane(s_ticket[1]);
     __syncthreads();
-    if (ticket < x_count && tid == 0) drawn = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (next_ticket < x_count && tid == 0) drawn = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     const int nk = p.K / BK;                           // >= 3 (launch_gemm_f32)
     TilePtrs cur_t, nxt_t;
     int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
-    bool have_next = false;
     int cur = 0, skip = 0;
     if (ticket < x_count) {
         tile_ptrs(ticket, cur_t, m0, n0);
@@ -627,57 +637,87 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_persistent_kernel(const G
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-        int next_ticket = x_count;
+        const bool have_next = next_ticket < x_count;
+        if (have_next) tile_ptrs(next_ticket, nxt_t, m0n, n0n);
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt == 0 && tid == 0) s_ticket[1] = drawn;            // resolved a whole tile (or the prologue) after it was requested
             if (skip > 0) --skip;                                     // landed before the previous epilogue's stores were issued
-            else if (kt + 1 < nk || have_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the s_ticket store above (and nothing else) is done
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // every step issues one DMA step (below), so one may stay in flight
             __builtin_amdgcn_s_barrier();
-            if (kt == 0) {
-                next_ticket = __builtin_amdgcn_readfirstlane(s_ticket[1]);
-                have_next = next_ticket < x_count;
-                if (have_next) {
-                    tile_ptrs(next_ticket, nxt_t, m0n, n0n);
-                    if (tid == 0) drawn = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            const float* As = &smem[cur][0][0];
-            const float* Ws = &smem[cur][1][0];
-            const int nxt = cur == 2 ? 0 : cur + 1;
+            // Fragment reads as inline asm: hipcc's waitcnt pass guards every LDS read it can see behind an LDS-DMA with vmcnt(0)
+            // (it cannot tell the stage being read from the stage being filled), i.e. it would drain the pipeline twice per K-step.
+            // The waits are explicit, and carry the fragment registers as operands so that the MFMAs cannot move above them.
+            const unsigned base = smem_base + cur * (2 * GBM * BK * 4);
             const int fill = cur == 0 ? 2 : cur - 1;                 // the stage read during the previous step
+            f32x4 a0, a1, b0, b1, c0, c1, d0, d1;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(base + off_a0));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1) : "v"(base + off_a0));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b0) : "v"(base + off_b0));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(b1) : "v"(base + off_b0));
+            {   // one DMA step per K-step, branch-free: this tile's step kt+2, else the next tile's step kt+2-nk, else (no next tile) a
+                // redundant re-fetch of this tile's last step into a stage nobody reads again -- it keeps the wait above a constant
+                const bool into_next = kt + 2 >= nk;
+                const int kk = into_next ? (have_next ? kt + 2 - nk : nk - 1) : kt + 2;
+                TilePtrs t;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int po = q ? po1 : po0;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ra + po);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
-                if (q == 0) {
-                    if (kt + 2 < nk) dma(fill, cur_t, kt + 2);
-                    else if (have_next) dma(fill, nxt_t, kt + 2 - nk);
+                for (int j = 0; j < 2; ++j) {
+                    t.a[j] = (into_next && have_next) ? nxt_t.a[j] : cur_t.a[j];
+                    t.w[j] = (into_next && have_next) ? nxt_t.w[j] : cur_t.w[j];
                 }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
-                }
+                dma(fill, t, kk);
             }
-            cur = nxt;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+            // Order as hipcc schedules the one-tile kernel (issuing the second four reads BEFORE the first sixteen MFMAs measured
+            // 7-9 % slower, twice): fourteen MFMAs, the second four reads, two MFMAs, their wait, sixteen MFMAs.
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][1], 0, 0, 0);
+                if (jj == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(c0) : "v"(base + off_a1));
+                    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(c1) : "v"(base + off_a1));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(d0) : "v"(base + off_b1));
+                    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(d1) : "v"(base + off_b1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[jj], d0[jj], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0[jj], d1[jj], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[jj], d0[jj], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[jj], d1[jj], acc[1][1], 0, 0, 0);
+            }
+            cur = cur == 2 ? 0 : cur + 1;
         }
         // The next tile's first two K-steps were requested during the last two steps above: let them land BEFORE this tile's stores
         // are issued (one counter for loads and stores: a counted wait behind 64 stores would wait for the stores' round trips).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The builtin, not an asm wait: the waitcnt pass must see that thread 0's ticket request has completed as well.
+        // The bias values are requested here, in front of that wait: a load that is still pending (as far as the pass can tell) when
+        // control returns to the K loop would be guarded there by a vmcnt(0) in front of every fragment read that reuses its register.
+        float bias_pre[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) bias_pre[tj] = p.bias ? p.bias[min(n0 + wc * 64 + tj * 32 + l31, p.N - 1)] : 0.f;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
         skip = have_next ? 2 : 0;
-        gemm_epilogue_of_kind<KIND>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (tid == 0) {
+            const int t2 = have_next ? drawn : x_count;               // ticket of the tile after the next one
+            s_ticket[0] = t2;
+            if (t2 < x_count) drawn = __hip_atomic_fetch_add(&tickets[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0): the LDS store above
+        __builtin_amdgcn_s_barrier();
+        const int after_next = __builtin_amdgcn_readfirstlane(s_ticket[0]);
+        gemm_epilogue_of_kind<KIND>(p, acc, m0, n0, wr, wc, l31, hh, bias_pre);
         ticket = next_ticket;
+        next_ticket = after_next;
         cur_t = nxt_t;
         m0 = m0n;
         n0 = n0n;
-        have_next = false;
     }
     if (tid == 0) {
         const int gone = __hip_atomic_fetch_add(&tickets[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
