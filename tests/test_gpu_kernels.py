@@ -73,6 +73,26 @@ def test_gemm_many_tiles(lib, M, N, K, act, use_res):
         assert err < 2e-5 * max(1.0, ref.abs().max().item()), (rep, err)
 
 
+def test_gemm_probe_build_stamps(lib):
+    """The probe build of the LDS-DMA GEMM (tools/gemm_stamps.py) computes the same product and leaves ordered wall-clock stamps and a
+    plausible placement per workgroup."""
+    M, N, K = 1000, 640, 256
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    C = torch.empty(M, N, device="cuda")
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    stamps = torch.zeros(tiles, 8, dtype=torch.int64, device="cuda")
+    assert lib.wt_dbg_gemm_stamps(P(Ad), K, P(Wd), P(bd), None, P(C), M, N, K, 0, P(stamps), _stream()) == 0
+    torch.cuda.synchronize()
+    ref = F.linear(A.double(), W.double(), b.double())
+    assert (C.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    s = stamps.cpu().numpy()
+    assert ((s[:, 1] & 0xF) < 8).all()                                  # XCC_ID
+    entry, first, loop_done, drained, issued = s[:, 2], s[:, 3], s[:, 4], s[:, 5], s[:, 6]
+    assert (entry > 0).all() and (entry <= first).all() and (first <= loop_done).all() and (loop_done <= issued).all() and (issued <= drained).all()
+    assert (drained - entry).max() < 100 * 1000                         # 100 MHz clock: every workgroup done within a millisecond
+
+
 @pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
     (128, 128, 64, 0, 0, False), (200, 136, 240, 1, 1, False), (1500, 384, 384, 0, 0, True), (97, 1000, 1536, 1, 1, False),
     (3000, 128, 240, 1, 1, False), (33, 51, 8, 0, 0, False), (1024, 3072, 1024, 0, 0, True),
