@@ -153,7 +153,10 @@ int wt_engine_get_timer(wt_engine* e, const char* which, wt_kernel_timer* out);
 int wt_decoder_time_cross_attention(wt_engine* dec, int iters, float* avg_us, void* stream);
 /* the same for any of the seven per-layer launches of a decode step: which = "qkv" (LN + q|k|v GEMV + KV append), "self_attn",
  * "pair" (self out-projection + folded cross query), "cross_attn", "cross_out" (split merge + cross out-projection), "fc1", "fc2".
- * The residual stream is not advanced (every launch reads the buffers as they stand).  Synchronises. */
+ * The residual stream is not advanced (every launch reads the buffers as they stand).  Synchronises.  Call it only BETWEEN
+ * steps of a decode (after a wt_decoder_poll): the launches overwrite the step scratch (query, attention context, FFN buffer,
+ * second residual buffer, split partials and the self-cache row at the current length) -- all of which the next step
+ * rewrites before it reads them, so the decode itself is not disturbed. */
 int wt_decoder_time_kernel(wt_engine* dec, const char* which, int iters, float* avg_us, void* stream);
 
 /* ---- log-mel front-end: replaces the CPU numpy STFT inside the reference's timed loop,

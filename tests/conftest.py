@@ -10,9 +10,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# The library reads its A/B tuning switches (WT_NSPLIT_SELF, WT_NO_FUSED_ARGMAX, ...) only when WT_TUNING=1 (csrc/wt_common.h:
+# tuning_env, latched at first use); a few tests exercise non-default paths through them, so the test process opts in.
+os.environ.setdefault("WT_TUNING", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: opt-in (WT_RUN_SLOW=1): minutes of host CPU for the oracle at the headline workload's full size")
 
 
 @pytest.fixture(scope="session")

@@ -494,7 +494,7 @@ struct StepIO {
 // wt_decoder_time_kernel replays one kind over all layers.
 enum { LP_QKV = 0, LP_SELF_ATTN, LP_PAIR, LP_CROSS_ATTN, LP_CROSS_OUT, LP_FC1, LP_FC2, LP_COUNT };
 static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, float* h1, int part, hipStream_t s) {
-    static const bool defer = getenv("WT_NO_DEFER_MERGE") == nullptr;  // A/B switch
+    static const bool defer = tuning_env("WT_NO_DEFER_MERGE") == nullptr;  // A/B switch
     const int d = e->d, B = io.B, H = e->H;
     const DecLayerW& l = e->dec_layers[i];
     float* sk = io.self_k + (size_t)i * B * H * io.self_cap * HEAD_DIM;
@@ -652,6 +652,7 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         if (idx >= 0 && idx <= e->dec_maxlen_cap) forced[idx] = tok;
     }
     if (!e->tables_valid || mask != e->h_mask || forced != e->h_forced) {
+        e->tables_valid = false;   // a failed upload below must not leave "valid" tables whose host images already hold the new rules
         e->h_mask.swap(mask);
         e->h_forced.swap(forced);
         HIPCHK(hipMemcpyAsync(e->mask, e->h_mask.data(), e->h_mask.size(), hipMemcpyHostToDevice, s));
@@ -681,13 +682,13 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     // implemented and tested, and measured a wash at medium.en batch 8: self-attention 9.0 -> 7.6 us at 447 keys, the pair launch
     // 8.2 -> 9.7 us (its blocks stage and merge two partial sets), 1.659 vs 1.649 ms per step in one A/B on one box.
     {
-        const bool can_defer = getenv("WT_NO_DEFER_MERGE") == nullptr && e->d <= 1024;
-        const int want = getenv("WT_NSPLIT_SELF") ? atoi(getenv("WT_NSPLIT_SELF")) : 1;
+        const bool can_defer = tuning_env("WT_NO_DEFER_MERGE") == nullptr && e->d <= 1024;
+        const int want = tuning_env("WT_NSPLIT_SELF") ? atoi(tuning_env("WT_NSPLIT_SELF")) : 1;
         const int ns = (want == 2 && can_defer) ? 2 : 1;
         if (ns != e->nsplit_self) e->graph_valid = false;
         e->nsplit_self = ns;
     }
-    e->nsplit_cross = getenv("WT_NSPLIT_CROSS") ? atoi(getenv("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
+    e->nsplit_cross = tuning_env("WT_NSPLIT_CROSS") ? atoi(tuning_env("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
     LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s));  // input of step 0
     rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, s);
@@ -702,7 +703,7 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
     io.embed = false;  // dh already holds this step's input: written by wt_decoder_begin (step 0) or by the previous greedy_finish
-    static const bool fuse = getenv("WT_NO_FUSED_ARGMAX") == nullptr;  // A/B switch: logits to HBM + greedy_select_kernel
+    static const bool fuse = tuning_env("WT_NO_FUSED_ARGMAX") == nullptr;  // A/B switch: logits to HBM + greedy_select_kernel
     SelectParams sp;
     memset(&sp, 0, sizeof sp);
     sp.logits = e->logits; sp.mask = e->mask; sp.forced = e->forced; sp.ids = e->ids; sp.unfinished = e->unfinished;
@@ -866,56 +867,41 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
 }
 
 // ------------------------------------------------------------------------------------------------- profiling
-// Average launch time of the dominant decode kernel (cross-attention) measured the way the decode step runs it:
-// the L per-layer launches over the engine's resident cross-KV caches are captured into a hipGraph, the graph is
-// replayed `iters` times between two hipEvents recorded on the launch stream, and the elapsed time is divided by
-// iters * L.  (Events cannot bracket single kernels inside the step graph; an eager pass adds dispatch gaps.)
-extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* avg_us, void* stream) {
-    if (!e || e->kind != WT_KIND_DECODER || !avg_us || iters < 1) return fail(WT_E_INVALID, "wt_decoder_time_cross_attention: bad arguments");
-    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_time_cross_attention needs a decode in flight (wt_decoder_begin)");
-    DeviceGuard guard(e->device);
-    HIPCHK(guard.err);
-    hipStream_t s = (hipStream_t)stream;
-    hipGraph_t g = nullptr;
+// Replays graph `g` (captured by the caller; consumed here) `iters` times between two hipEvents on `s`; every exit path releases
+// the graph, its executable and the events.
+static int replay_and_time(hipGraph_t g, int iters, int launches_per_replay, float* avg_us, hipStream_t s) {
     hipGraphExec_t ge = nullptr;
-    HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
-    hipError_t le = hipSuccess;
-    for (int i = 0; i < e->L && le == hipSuccess; ++i) {
-        DecAttnParams a;
-        memset(&a, 0, sizeof a);
-        a.q = e->dq; a.kcache = e->cross_k + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
-        a.vcache = e->cross_v + (size_t)i * e->B * e->H * e->S * HEAD_DIM;
-        a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = e->B; a.H = e->H; a.s_cap = e->S;
-        a.n_split = e->nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads;
-        a.ln_h = e->dh2; a.ln_r = e->dec_layers[i].fold_r; a.ln_t = e->dec_layers[i].fold_t;  // as in the decode step
-        a.defer_merge = e->nsplit_cross == 2 && getenv("WT_NO_DEFER_MERGE") == nullptr;
-        le = launch_dec_attn(a, e->own_stream);
-    }
-    hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
-    if (le != hipSuccess || ce != hipSuccess) return fail(WT_E_HIP, "capturing the cross-attention timing graph failed");
-    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    HIPCHK(hipGraphLaunch(ge, s));  // warm-up replay (replayed on the caller's stream, like the decode step)
-    HIPCHK(hipEventRecord(a, s));
-    for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(ge, s));
-    HIPCHK(hipEventRecord(b, s));
-    HIPCHK(hipEventSynchronize(b));
+    hipEvent_t a = nullptr, b = nullptr;
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, a, b));
-    *avg_us = ms * 1e3f / ((float)iters * e->L);
-    hipEventDestroy(a);
-    hipEventDestroy(b);
-    hipGraphExecDestroy(ge);
+    hipError_t he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (he == hipSuccess) he = hipEventCreate(&a);
+    if (he == hipSuccess) he = hipEventCreate(&b);
+    if (he == hipSuccess) he = hipGraphLaunch(ge, s);  // warm-up replay (replayed on the caller's stream, like the decode step)
+    if (he == hipSuccess) he = hipEventRecord(a, s);
+    for (int i = 0; i < iters && he == hipSuccess; ++i) he = hipGraphLaunch(ge, s);
+    if (he == hipSuccess) he = hipEventRecord(b, s);
+    if (he == hipSuccess) he = hipEventSynchronize(b);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, a, b);
+    if (a) hipEventDestroy(a);
+    if (b) hipEventDestroy(b);
+    if (ge) hipGraphExecDestroy(ge);
     hipGraphDestroy(g);
+    if (he != hipSuccess) return fail(WT_E_HIP, "timing replay failed: %s", hipGetErrorString(he));
+    *avg_us = ms * 1e3f / ((float)iters * launches_per_replay);
     return WT_OK;
 }
 
-// Average launch time (us) of ONE kind of decode-step launch (LP_* above), measured like wt_decoder_time_cross_attention: the L
+extern "C" int wt_decoder_time_cross_attention(wt_engine* e, int iters, float* avg_us, void* stream) {
+    return wt_decoder_time_kernel(e, "cross_attn", iters, avg_us, stream);
+}
+
+// Average launch time (us) of ONE kind of decode-step launch (LP_* above), measured the way the decode step runs it: the L
 // per-layer launches of that kind (each layer's own weights / caches, so nothing is cache-resident that would not be in the real
-// step) are captured into a hipGraph and replayed `iters` times between two hipEvents.  The residual stream is not advanced:
-// every launch reads the current buffers, which is what its duration depends on.
+// step) are captured into a hipGraph and replayed `iters` times between two hipEvents recorded on the launch stream.  (Events
+// cannot bracket single kernels inside the step graph; an eager pass adds dispatch gaps.)  The residual stream is not advanced:
+// every launch reads the current buffers, which is what its duration depends on.  Only to be called BETWEEN steps of a decode:
+// the launches scribble on the step scratch (dq, datt, dh2, dffn, the attention partials and the self-cache row at self_len),
+// all of which the next step rewrites before reading.
 extern "C" int wt_decoder_time_kernel(wt_engine* e, const char* which, int iters, float* avg_us, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER || !which || !avg_us || iters < 1) return fail(WT_E_INVALID, "wt_decoder_time_kernel: bad arguments");
     if (!e->begun) return fail(WT_E_STATE, "wt_decoder_time_kernel needs a decode in flight (wt_decoder_begin)");
@@ -931,33 +917,21 @@ extern "C" int wt_decoder_time_kernel(wt_engine* e, const char* which, int iters
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
     io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross; io.embed = false; io.argmax = nullptr; io.argmax_parts = nullptr;
-    const bool was_profiling = e->profiling;
-    e->profiling = false;  // no event records inside the capture
+    struct ProfilingOff {   // no event records inside the capture; the caller's setting comes back on every exit path
+        wt_engine* e; bool was;
+        explicit ProfilingOff(wt_engine* e_) : e(e_), was(e_->profiling) { e->profiling = false; }
+        ~ProfilingOff() { e->profiling = was; }
+    } profiling_off(e);
     hipGraph_t g = nullptr;
-    hipGraphExec_t ge = nullptr;
     HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
     int rc = WT_OK;
     for (int i = 0; i < e->L && rc == WT_OK; ++i) rc = enqueue_layer_part(e, io, i, e->dh, e->dh2, part, e->own_stream);
     hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
-    e->profiling = was_profiling;
-    if (rc != WT_OK || ce != hipSuccess) return fail(WT_E_HIP, "capturing the timing graph of '%s' failed", which);
-    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    HIPCHK(hipGraphLaunch(ge, s));  // warm-up replay
-    HIPCHK(hipEventRecord(a, s));
-    for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(ge, s));
-    HIPCHK(hipEventRecord(b, s));
-    HIPCHK(hipEventSynchronize(b));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, a, b));
-    *avg_us = ms * 1e3f / ((float)iters * e->L);
-    hipEventDestroy(a);
-    hipEventDestroy(b);
-    hipGraphExecDestroy(ge);
-    hipGraphDestroy(g);
-    return WT_OK;
+    if (rc != WT_OK || ce != hipSuccess) {
+        if (g) hipGraphDestroy(g);
+        return fail(WT_E_HIP, "capturing the timing graph of '%s' failed", which);
+    }
+    return replay_and_time(g, iters, e->L, avg_us, s);
 }
 
 extern "C" int wt_engine_set_profiling(wt_engine* e, int enabled) {

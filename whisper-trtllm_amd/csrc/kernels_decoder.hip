@@ -372,7 +372,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 if (am_tr) am_tr[n] = v;
                 const uint8_t mk = am_mk[cur];
                 if ((mk & 1) || ((mk & 2) && am_at_begin)) v = -INFINITY;
-                if (v > am_best || (v == am_best && n < am_bidx)) {
+                if (argmax_better(v, n, am_best, am_bidx)) {
                     am_best = v;
                     am_bidx = n;
                 }
@@ -415,7 +415,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             for (int i = 0; i < NW * 2; ++i) {
                 const float v = cv[i * NB + tid];
                 const int ix = ci[i * NB + tid];
-                if (v > best || (v == best && ix < bidx)) {
+                if (argmax_better(v, ix, best, bidx)) {
                     best = v;
                     bidx = ix;
                 }
@@ -465,7 +465,7 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out, int tg_ove
     // the second pair prefetched behind the first (A/B knob: WT_SKINNY_TARGET)
     // (only the 8-row template: batch 16 measured 424 audio-s/s with 2048 and 398 with 1024; batch 1 / 2 / 4: 1.07 / 1.11 / 1.24 ms
     //  per step with 2048 and 1.09 / 1.12 / 1.27 with 1024; batch 6: 1.44 vs 1.41)
-    static const int tg_total = getenv("WT_SKINNY_TARGET") ? atoi(getenv("WT_SKINNY_TARGET")) : (NB == 8 ? 1024 : 2048);
+    static const int tg_total = tuning_env("WT_SKINNY_TARGET") ? atoi(tuning_env("WT_SKINNY_TARGET")) : (NB == 8 ? 1024 : 2048);
     const int target_groups = (tg_override > 0 ? tg_override : tg_total) / nsplit;
     int rows_per_group = 2 * ((p.N + 2 * target_groups - 1) / (2 * target_groups));
     if (rows_per_group < 2) rows_per_group = 2;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     static int variant = -1;  // A/B override: WT_ATTN_VARIANT=0 forces default-policy loads, 1 forces non-temporal loads
     if (variant < 0) {
-        const char* e = getenv("WT_ATTN_VARIANT");
+        const char* e = tuning_env("WT_ATTN_VARIANT");
         variant = e ? atoi(e) : 2;
     }
     const dim3 grid(p.n_split, p.H, p.B);
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
     int bidx = 0x7fffffff;
     auto consider = [&](float x, uint8_t mk, int v) {
         if ((mk & 1) || ((mk & 2) && at_begin)) x = -INFINITY;
-        if (x > best || (x == best && v < bidx)) {
+        if (argmax_better(x, v, best, bidx)) {
             best = x;
             bidx = v;
         }
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
     for (int o = 32; o >= 1; o >>= 1) {
         const float ov = __shfl_xor(best, o);
         const int oi = __shfl_xor(bidx, o);
-        if (ov > best || (ov == best && oi < bidx)) {
+        if (argmax_better(ov, oi, best, bidx)) {
             best = ov;
             bidx = oi;
         }
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
     __syncthreads();
     if (tid == 0) {
         for (int i = 1; i < 4; ++i)
-            if (s_val[i] > best || (s_val[i] == best && s_idx[i] < bidx)) {
+            if (argmax_better(s_val[i], s_idx[i], best, bidx)) {
                 best = s_val[i];
                 bidx = s_idx[i];
             }
@@ -847,14 +847,14 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
         if (b < p.B) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (l + k * lpb < p.n_parts && (pv[k] > best || (pv[k] == best && pi[k] < bidx))) {
+                if (l + k * lpb < p.n_parts && argmax_better(pv[k], pi[k], best, bidx)) {
                     best = pv[k];
                     bidx = pi[k];
                 }
             for (int i = l + 8 * lpb; i < p.n_parts; i += lpb) {
                 const float v = p.part_val[pbase + i];
                 const int ix = p.part_idx[pbase + i];
-                if (v > best || (v == best && ix < bidx)) {
+                if (argmax_better(v, ix, best, bidx)) {
                     best = v;
                     bidx = ix;
                 }
@@ -863,13 +863,14 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
         for (int o = lpb >> 1; o >= 1; o >>= 1) {   // lpb <= 64 and a power of two: a group never straddles a wave
             const float ov = __shfl_xor(best, o);
             const int oi = __shfl_xor(bidx, o);
-            if (ov > best || (ov == best && oi < bidx)) {
+            if (argmax_better(ov, oi, best, bidx)) {
                 best = ov;
                 bidx = oi;
             }
         }
         if (b < p.B && l == 0) {
             int tok = bidx;
+            if ((unsigned)tok >= (unsigned)p.V) tok = p.eos;      // unreachable with a NaN-aware argmax; never index the embedding out of range
             if (forced >= 0) tok = forced;
             if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
             if (!unf) tok = p.pad;                                 // finished rows keep emitting pad

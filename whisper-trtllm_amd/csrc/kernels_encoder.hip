@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
         // ... everyone's has, and nobody still reads the stage refilled next (the fragment reads of step kt-1 were waited for
         // before its MFMAs).  A raw s_barrier: __syncthreads() would add a vmcnt(0) fence and undo the counted wait.
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");   // the builtin is IntrNoMem: without this the LDS fragment reads below may be hoisted above it
         if (STAMP && kt == 0) t_first = wall_clock64();
         const float* As = &smem[cur][0][0];
         const float* Ws = &smem[cur][1][0];
@@ -520,7 +521,7 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<16>());
         if (e != hipSuccess) return e;
-        const char* ev = getenv("WT_GEMM_BK");
+        const char* ev = tuning_env("WT_GEMM_BK");
         force_bk = ev ? atoi(ev) : 0;
         attr_set.set();
     }
@@ -530,7 +531,7 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
     const int tiles = nbx * nby;
     int bk = 16;
     if (force_bk == 16 || force_bk == 32) bk = force_bk;
-    static const bool no_dma = getenv("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
+    static const bool no_dma = tuning_env("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
     if (!no_dma && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
     {
         if (p.dbg_stamps) hipLaunchKernelGGL(gemm_f32_dma_kernel<true>, dim3(tiles), dim3(256), 0, s, p);

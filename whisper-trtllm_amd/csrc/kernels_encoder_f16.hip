@@ -772,19 +772,19 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
         if (e != hipSuccess) return e;
-        const char* ev = getenv("WT_HGEMM_BK");
+        const char* ev = tuning_env("WT_HGEMM_BK");
         if (ev && (atoi(ev) == 32 || atoi(ev) == 64)) bk = atoi(ev);
         attr_set.set();
     }
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
     const dim3 grid(nbx * nby);
-    static const bool no_dma = getenv("WT_HGEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
+    static const bool no_dma = tuning_env("WT_HGEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
     // A/B override: WT_HGEMM_VARIANT=2 forces the 128x128 two-stage kernel, 3 the 256x128 three-stage kernel wherever M >= 1024.
     // Default (measured, TFLOP/s, 128x128 two-stage vs 256x128 three-stage software-pipelined; N / K / epilogue):
     //   M = 12000: 3072/1024 688 vs 655, 1024/1024 588 vs 512, 4096/1024 GELU fp16-out 604 vs 593, 1024/4096 805 vs 756, 1024/3072 732 vs 668
     //   M = 24000: 3072/1024 687 vs 712, 1024/1024 678 vs 682, 4096/1024 GELU fp16-out 622 vs 610, 1024/4096 823 vs 904, 1024/3072 773 vs 840
     // -> the big tile pays once there are >= ~3 rounds of 256x128 tiles per CU (batch 16); the 128x128 tiles fill the chip better below.
-    static const int env_variant = getenv("WT_HGEMM_VARIANT") ? atoi(getenv("WT_HGEMM_VARIANT")) : 0;
+    static const int env_variant = tuning_env("WT_HGEMM_VARIANT") ? atoi(tuning_env("WT_HGEMM_VARIANT")) : 0;
     const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach both kernels at small sizes
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
     const bool use3 = variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 ? false : p.M >= 16384;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "host_logic.h"  // HEAD_DIM, BlobHeader / BlobTensor, EngineDims (host-only part, also built under ASan/UBSan)
 
@@ -96,6 +97,21 @@ struct DecAttnParams {
     const float* ln_r;     // [d] row sums of s.Wq.diag(gamma)
     const float* ln_t;     // [d] s.(Wq.beta + bq)
 };
+
+// A/B tuning switches (WT_NSPLIT_CROSS, WT_GEMM_NO_DMA, ...; DESIGN.md "Tuning knobs") are lab tools, not part of the C-ABI's
+// contract: they are read ONLY when the process also sets WT_TUNING=1, so a stray variable in a production environment cannot
+// change what the library behind the ABI does.
+inline const char* tuning_env(const char* name) {
+    static const bool on = [] { const char* t = getenv("WT_TUNING"); return t && t[0] == '1'; }();
+    return on ? getenv(name) : nullptr;
+}
+
+// torch.argmax semantics (the reference's greedy step, run.py:205): NaN counts as the maximum, the lowest index wins ties.
+// True when candidate (v, i) beats the running (best, bidx).
+__device__ __forceinline__ bool argmax_better(float v, int i, float best, int bidx) {
+    const bool vn = v != v, bn = best != best;
+    return vn ? (!bn || i < bidx) : (!bn && (v > best || (v == best && i < bidx)));
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property: a launcher keeps one "done" flag per device
 // (`static PerDeviceFlag f; if (!f.get()) { ...set...; f.set(); }`), so a second device opened in the same process gets
