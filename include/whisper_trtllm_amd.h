@@ -71,7 +71,8 @@ typedef struct wt_engine wt_engine;
 /* model hyper-parameters baked into the blob (HF config keys, build_encoder.py:48-56 / build_decoder.py:45-56) */
 typedef struct {
     int32_t kind;      /* wt_engine_kind */
-    int32_t precision; /* wt_dtype of the weights/compute: WT_F32 */
+    int32_t precision; /* wt_dtype of the GEMM / GEMV weight operands: WT_F32, or WT_F16 (--engine_precision float16, builder.py:55;
+                          accumulation, LayerNorm, softmax, residual stream and every Session-visible tensor stay fp32) */
     int32_t d_model, n_heads, n_layers, ffn_dim;
     int32_t n_mels, max_source_positions, max_target_positions, vocab_size;
 } wt_engine_info;
@@ -120,7 +121,9 @@ typedef struct {
 /* (6) start a greedy decode of `batch` utterances (1 <= batch <= 16 per call, WT_E_UNSUPPORTED above; shard larger
  * batches over calls or GPUs): project the encoder memory f32 [batch,S,d] into the
  * resident cross-KV cache, reset the self-KV cache and the id buffer to [[decoder_start_token_id]]*batch.
- * Replaces greedy_search() step 0 (run.py:171-197 with past_key_values=None).  Asynchronous when the token rules
+ * Replaces greedy_search() step 0 (run.py:171-197 with past_key_values=None).  An fp16 engine keeps these RESIDENT caches in fp16
+ * (they never leave the engine; the by-value caches of wt_engine_run stay f32 like the reference's, model.py:464-468).
+ * Asynchronous when the token rules
  * (suppress / begin-suppress / forced lists) equal those of the previous decode on this handle; a changed rule set is
  * uploaded and the stream synchronised once. */
 int wt_decoder_begin(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p, void* stream);

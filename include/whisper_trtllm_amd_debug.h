@@ -60,6 +60,22 @@ int wt_dbg_skinny_pair(const float* Xa, const float* Wa, const float* bias_a, co
                        const float* Xb, const float* Xb2, const float* Wb, const float* bias_b, float* Yb, int Nb, int Kb, int B,
                        void* stream);
 
+/* ---- fp16 decoder engines: IEEE-half weights (`W`, `Wa`, `Wb`) and / or IEEE-half K/V caches; activations, accumulation, LayerNorm,
+ * softmax and outputs are fp32.  Arguments as in the fp32 hooks of the same name. */
+int wt_dbg_skinny_f16(const float* X, const float* ln_w, const float* ln_b, const void* W, const float* bias, const float* resid, float* Y,
+                      int B, int N, int K, int xmode, int act, float scale, void* stream);
+/* ln_h / ln_r / ln_t: all null (plain query) or all set (folded query) */
+int wt_dbg_decode_attention_f16(const float* q, const void* kcache, const void* vcache, float* part, int* cnt, float* out, const float* ln_h,
+                                const float* ln_r, const float* ln_t, int B, int H, int s_cap, int len, int n_split, void* stream);
+/* two key splits, merge deferred into the out-projection (half caches, half W) */
+int wt_dbg_attention_then_projection_f16(const float* q, const void* kcache, const void* vcache, float* part, const void* W, const float* bias,
+                                         const float* resid, float* Y, int B, int H, int s_cap, int len, void* stream);
+int wt_dbg_skinny_pair_f16(const float* Xa, const void* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka, const float* Xb,
+                           const float* Xb2, const void* Wb, const float* bias_b, float* Yb, int Nb, int Kb, int B, void* stream);
+/* cross-K/V projection: A half [B][rows_total][H*64] (the first `rows` rows of every utterance), W half [2*H*64][H*64], bias f32 ->
+ * K / V caches [B][H][kv_cap][64], rows [seq_off, seq_off + rows), stored as half (out_half) or f32 */
+int wt_dbg_gemm_f16_kv(const void* A, int rows_total, const void* W, const float* bias, void* kcache, void* vcache, int B, int rows, int H,
+                       int kv_cap, int seq_off, int out_half, void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,8 @@ static void check_accepted(const ParsedBlob& pb, const std::vector<unsigned char
     if (touched == 0xffffffffffffffffULL) puts("");  // keep the reads alive
     const EngineDims& e = pb.dims;
     CHECK(e.d > 0 && e.d <= 1024 && e.d == e.H * 64 && e.F > 0 && e.F <= 4096 && e.L > 0, "dims");
-    if (e.precision == WT_F16) CHECK(e.F >= e.d, "fp16 engine with ffn_dim < d_model accepted");
+    if (e.precision == WT_F16 && e.kind == WT_KIND_ENCODER) CHECK(e.F >= e.d, "fp16 encoder with ffn_dim < d_model accepted");
+    if (e.precision == WT_F16) CHECK((e.d & 7) == 0 && (e.F & 7) == 0, "fp16 engine whose d_model / ffn_dim is not a multiple of 8 accepted");
 }
 
 template <class T>
@@ -110,7 +111,9 @@ int main(int argc, char** argv) {
         put<uint32_t>(b, off_prec, WT_F16);
         put<int32_t>(b, off_cfg + 4 * CFG_FFN, hd.cfg[CFG_D_MODEL] / 2);
     } else {
-        put<uint32_t>(mk("fp16 decoder"), off_prec, WT_F16);
+        auto& b = mk("fp16 decoder with ffn_dim % 8 != 0");   // eight halves per 16-byte weight load
+        put<uint32_t>(b, off_prec, WT_F16);
+        put<int32_t>(b, off_cfg + 4 * CFG_FFN, hd.cfg[CFG_D_MODEL] + 4);
     }
     {
         auto& b = mk("truncated to the header");

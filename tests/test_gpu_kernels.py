@@ -423,3 +423,126 @@ def test_self_attention_two_splits_merged_by_both_halves_of_the_pair(lib, B, H, 
     assert torch.isfinite(h1).all() and torch.isfinite(u).all()
     assert (h1.cpu().double() - ref1).abs().max().item() < 3e-5
     assert (u.cpu().double() - ref2).abs().max().item() < 3e-5
+
+
+# ----------------------------------------------------------------------------- fp16 decoder engines: half weights / half K/V caches
+# The half operands are exact in fp64, so the references below differ from the kernels only by fp32 accumulation order: the same
+# tolerances as the fp32 kernels.
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 12, 16])
+@pytest.mark.parametrize("N,K,xmode,act,use_res", [
+    (384, 384, 1, 0, False), (1152, 384, 1, 0, False), (1536, 384, 1, 1, False), (384, 1536, 0, 0, True),
+    (1024, 1024, 1, 0, True), (1024, 4096, 0, 0, True), (768, 3072, 0, 1, False), (1001, 128, 1, 0, False),
+    (130, 2048, 0, 0, False), (7, 512, 0, 0, False), (51864, 384, 1, 0, False),
+    (2304, 768, 1, 0, False), (768, 768, 0, 0, True), (1536, 512, 1, 1, False), (512, 2048, 0, 0, True), (320, 192, 1, 1, False), (192, 320, 0, 0, True)])
+def test_skinny_half_weights(lib, B, N, K, xmode, act, use_res):
+    X, W, b = _rand(B, K, seed=9, scale=2.0) + 0.3, _rand(N, K, seed=10, scale=K ** -0.5).half(), _rand(N, seed=11)
+    g, be = _rand(K, seed=12) + 1.0, _rand(K, seed=13)
+    R = _rand(B, N, seed=14) if use_res else None
+    xin = F.layer_norm(X.double(), (K,), g.double(), be.double(), 1e-5) if xmode == 1 else X.double()
+    ref = (F.linear(xin, W.double(), b.double())) * 0.5
+    if act:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + R.double()
+    Xd, gd, bed, Wd, bd = X.cuda(), g.cuda(), be.cuda(), W.cuda(), b.cuda()
+    for nt in (0, 4):   # default-policy and non-temporal weight loads
+        Y = R.cuda().clone() if use_res else torch.full((B, N), float("nan"), device="cuda")
+        rc = lib.wt_dbg_skinny_f16(P(Xd), P(gd), P(bed), P(Wd), P(bd), P(Y) if use_res else None, P(Y), B, N, K, xmode | nt, act, 0.5, _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        err = (Y.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (nt, err)
+
+
+@pytest.mark.parametrize("folded", [False, True])
+@pytest.mark.parametrize("B,H,cap,length,n_split", [(1, 2, 40, 1, 1), (3, 2, 40, 17, 2), (2, 6, 1500, 1500, 8), (8, 2, 448, 447, 3), (1, 1, 96, 96, 16),
+                                                    (2, 3, 160, 5, 4), (1, 2, 64, 63, 1), (8, 16, 1500, 1500, 2), (16, 16, 1500, 1500, 1), (5, 8, 96, 33, 3)])
+def test_decode_attention_half_caches(lib, B, H, cap, length, n_split, folded):
+    """32 online-softmax streams of 8 lanes x 8 head dims over IEEE-half K/V caches, fp32 scores / softmax / accumulators."""
+    d = 64 * H
+    q = _rand(B, d, seed=15) * 0.5
+    h1 = _rand(B, d, seed=22) * 2.0 + 0.7
+    r, t = _rand(d, seed=23), _rand(d, seed=24) * 0.3
+    k, v = _rand(B, H, cap, 64, seed=16).half(), _rand(B, H, cap, 64, seed=17).half()
+    part = torch.full((B, H, n_split, 68), float("nan"), device="cuda")
+    cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+    out = torch.full((B, d), float("nan"), device="cuda")
+    qd, kd, vd, hd, rd, td = q.cuda(), k.cuda(), v.cuda(), h1.cuda(), r.cuda(), t.cuda()
+    for _ in range(3):  # the arrival tickets must re-arm themselves between launches
+        assert lib.wt_dbg_decode_attention_f16(P(qd), P(kd), P(vd), P(part), P(cnt), P(out), P(hd) if folded else None, P(rd) if folded else None,
+                                               P(td) if folded else None, B, H, cap, length, n_split, _stream()) == 0
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0
+    q64 = q.double()
+    if folded:
+        h64 = h1.double()
+        mu = h64.mean(1, keepdim=True)
+        rstd = (h64.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        q64 = (q64 - mu * r.double()) * rstd + t.double()
+    att = torch.softmax(q64.view(B, H, 1, 64) @ k.double()[:, :, :length].transpose(-1, -2), -1)
+    ref = (att @ v.double()[:, :, :length]).reshape(B, d)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("B,H,cap,length", [(8, 16, 1500, 1500), (3, 6, 1500, 1500), (2, 12, 200, 199), (16, 16, 1500, 1500), (5, 2, 96, 96), (11, 16, 448, 3)])
+def test_attention_with_deferred_merge_half(lib, B, H, cap, length):
+    """fp16 engine's cross-attention -> out-projection pair: half caches, two key splits left for the half-weight GEMV to merge."""
+    d = 64 * H
+    q = _rand(B, d, seed=41) * 0.5
+    k, v = _rand(B, H, cap, 64, seed=42).half(), _rand(B, H, cap, 64, seed=43).half()
+    W, bias, resid = _rand(d, d, seed=44, scale=d ** -0.5).half(), _rand(d, seed=45), _rand(B, d, seed=46)
+    qd, kd, vd, Wd, bd, rd = q.cuda(), k.cuda(), v.cuda(), W.cuda(), bias.cuda(), resid.cuda()
+    part = torch.full((B, H, 2, 68), float("nan"), device="cuda")
+    y = torch.full((B, d), float("nan"), device="cuda")
+    assert lib.wt_dbg_attention_then_projection_f16(P(qd), P(kd), P(vd), P(part), P(Wd), P(bd), P(rd), P(y), B, H, cap, length, _stream()) == 0
+    torch.cuda.synchronize()
+    qh = q.double().view(B, H, 1, 64)
+    a64 = (torch.softmax(qh @ k.double()[:, :, :length].transpose(-1, -2), -1) @ v.double()[:, :, :length]).reshape(B, d)
+    ref = resid.double() + a64 @ W.double().T + bias.double()
+    assert (y.cpu().double() - ref).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 8, 11, 16])
+@pytest.mark.parametrize("d", [128, 384, 512, 768, 1024])
+def test_skinny_pair_half_weights(lib, B, d):
+    a, h = _rand(B, d, seed=31), _rand(B, d, seed=32)
+    Wo, bo = _rand(d, d, seed=33, scale=d ** -0.5).half(), _rand(d, seed=34)
+    Wf, c = _rand(d, 2 * d, seed=35, scale=(2 * d) ** -0.5).half(), _rand(d, seed=36)
+    ad, hd, Wod, bod, Wfd, cd = a.cuda(), h.cuda(), Wo.cuda(), bo.cuda(), Wf.cuda(), c.cuda()
+    h1 = torch.full((B, d), float("nan"), device="cuda")
+    uo = torch.full((B, d), float("nan"), device="cuda")
+    assert lib.wt_dbg_skinny_pair_f16(P(ad), P(Wod), P(bod), P(hd), P(h1), d, d, P(ad), P(hd), P(Wfd), P(cd), P(uo), d, 2 * d, B, _stream()) == 0
+    torch.cuda.synchronize()
+    ref1 = h.double() + a.double() @ Wo.double().T + bo.double()
+    ref2 = torch.cat([a, h], 1).double() @ Wf.double().T + c.double()
+    assert (h1.cpu().double() - ref1).abs().max().item() < 2e-5
+    assert (uo.cpu().double() - ref2).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("out_half", [1, 0])
+@pytest.mark.parametrize("B,H,rows_total,rows,cap,seq_off", [(2, 2, 96, 96, 96, 0), (3, 6, 1500, 1500, 1500, 0), (1, 2, 96, 85, 96, 11), (2, 3, 160, 160, 160, 0),
+                                                             (1, 16, 1500, 1, 1500, 1499), (8, 16, 1500, 1500, 1500, 0)])
+def test_cross_kv_projection_f16(lib, B, H, rows_total, rows, cap, seq_off, out_half):
+    """The fp16 GEMM writing head-split K / V caches [b][h][cap][64] (fp16 resident caches, or the f32 caches of the Session path);
+    partial row ranges = the engine-only 'partial cross cache' protocol (model.py:264-272).  Untouched cache rows keep their content."""
+    d = 64 * H
+    A = _rand(B, rows_total, d, seed=51).half()
+    W, bias = _rand(2 * d, d, seed=52, scale=d ** -0.5).half(), _rand(2 * d, seed=53)
+    dt = torch.float16 if out_half else torch.float32
+    kc = torch.full((B, H, cap, 64), 7.0, device="cuda", dtype=dt)
+    vc = torch.full((B, H, cap, 64), 7.0, device="cuda", dtype=dt)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    assert lib.wt_dbg_gemm_f16_kv(P(Ad), rows_total, P(Wd), P(bd), P(kc), P(vc), B, rows, H, cap, seq_off, out_half, _stream()) == 0
+    torch.cuda.synchronize()
+    y = F.linear(A[:, :rows].double(), W.double(), bias.double())                       # [B, rows, 2d]
+    kr = y[..., :d].view(B, rows, H, 64).transpose(1, 2)
+    vr = y[..., d:].view(B, rows, H, 64).transpose(1, 2)
+    tol = (2e-3 if out_half else 2e-5) * max(1.0, float(y.abs().max()))
+    for got, ref in ((kc, kr), (vc, vr)):
+        g = got.cpu().double()
+        assert (g[:, :, seq_off:seq_off + rows] - ref).abs().max().item() < tol
+        keep = torch.ones(cap, dtype=torch.bool)
+        keep[seq_off:seq_off + rows] = False
+        assert (g[:, :, keep] == 7.0).all()

@@ -85,9 +85,7 @@ def test_fp16_encoder_engine(wt, case):
     dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
     ids = dec.generate(h16).cpu().numpy()
     assert ids.shape[0] == mel.shape[0] and (ids[:, 0] == cfg["decoder_start_token_id"]).all()
-    assert wt.Builder().build_engine is not None
-    with pytest.raises(AssertionError):
-        wt.convert.build_decoder_engine(cfg, weights, precision="float16")   # decoder stays fp32
+    # (fp16 DECODER engines: tests/test_gpu_fp16_decoder.py)
 
 
 def test_batches_larger_than_sixteen_are_chunked(wt):
@@ -214,3 +212,27 @@ def test_steps_past_max_length_do_not_touch_the_logits_trace(wt):
     assert (cur2, done2) == (ml, True)
     assert torch.equal(buf, snap) and (buf[-guard:] == 777.0).all()
     np.testing.assert_array_equal(dec.read_ids(cur).cpu().numpy(), z["ids"])
+
+
+@pytest.mark.parametrize("precision", ["float32", "float16"])
+def test_nan_in_one_utterance_keeps_every_id_in_range(wt, precision):
+    """a NaN sample in one utterance's mel makes that row's logits NaN.  torch.argmax (the reference's greedy step, run.py:205)
+    counts NaN as the maximum and returns its first index, so the reference keeps emitting an in-range id; a plain `>` comparison
+    would leave the argmax at its sentinel and the next step would gather the token embedding 2^31 rows out of bounds.  The NaN
+    row must decode exactly as the oracle's (first non-suppressed index = 0 after the forced token), the other rows must not notice."""
+    import cpu_ref
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 3)
+    mel = wt.synthetic.make_mel(cfg, index=5, batch=3)
+    mel[1, 5, 17] = np.nan
+    enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights))
+    dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights, precision=precision), cfg)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    assert torch.isnan(hidden[1]).all() and torch.isfinite(hidden[0]).all() and torch.isfinite(hidden[2]).all()
+    ids = dec.generate(hidden).cpu().numpy()
+    assert ((ids >= 0) & (ids < cfg["vocab_size"])).all(), ids
+    W = cpu_ref.to_torch(cpu_ref.fp16_engine_weights(weights, decoder=True) if precision == "float16" else weights)
+    with torch.no_grad():
+        want = cpu_ref.greedy_search(W, cfg, hidden.cpu(), fp16_engine=precision == "float16").numpy()
+    np.testing.assert_array_equal(ids, want)
+    assert (ids[1, 2:] == 0).all()

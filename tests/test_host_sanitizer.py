@@ -25,12 +25,12 @@ def fuzzer(tmp_path_factory):
     return str(out)
 
 
-@pytest.mark.parametrize("kind,precision", [("encoder", "float32"), ("encoder", "float16"), ("decoder", "float32")])
+@pytest.mark.parametrize("kind,precision", [("encoder", "float32"), ("encoder", "float16"), ("decoder", "float32"), ("decoder", "float16")])
 def test_blob_parser_and_shape_inference_under_asan_ubsan(fuzzer, tmp_path, kind, precision):
     cfg = w.synthetic.get_config("toy-short")
     weights = w.synthetic.make_weights(cfg, 3)
     blob = (w.convert.build_encoder_engine(cfg, weights, precision=precision) if kind == "encoder"
-            else w.convert.build_decoder_engine(cfg, weights))
+            else w.convert.build_decoder_engine(cfg, weights, precision=precision))
     path = tmp_path / f"{kind}.engine"
     path.write_bytes(blob)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")

@@ -21,7 +21,8 @@ EXPORTS = [
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
 DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_decode_attention",
-                 "wt_dbg_decode_attention_folded", "wt_dbg_skinny_pair", "wt_dbg_attention_then_projection", "wt_dbg_self_attention_then_pair"]
+                 "wt_dbg_decode_attention_folded", "wt_dbg_skinny_pair", "wt_dbg_attention_then_projection", "wt_dbg_self_attention_then_pair",
+                 "wt_dbg_skinny_f16", "wt_dbg_decode_attention_f16", "wt_dbg_attention_then_projection_f16", "wt_dbg_skinny_pair_f16", "wt_dbg_gemm_f16_kv"]
 
 
 class TensorDesc(Structure):
@@ -110,6 +111,11 @@ def load():
     lib.wt_dbg_attention_then_projection.argtypes = [P, P, P, P, P, P, P, P, I, I, I, I, I, P]
     lib.wt_dbg_skinny_pair.argtypes = [P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]
     lib.wt_dbg_self_attention_then_pair.argtypes = [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]
+    lib.wt_dbg_skinny_f16.argtypes = lib.wt_dbg_skinny.argtypes
+    lib.wt_dbg_decode_attention_f16.argtypes = [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]
+    lib.wt_dbg_attention_then_projection_f16.argtypes = [P, P, P, P, P, P, P, P, I, I, I, I, P]
+    lib.wt_dbg_skinny_pair_f16.argtypes = lib.wt_dbg_skinny_pair.argtypes
+    lib.wt_dbg_gemm_f16_kv.argtypes = [P, I, P, P, P, P, I, I, I, I, I, I, P]
     if lib.wt_abi_version() != ABI_VERSION:
         raise EngineLibraryError(f"ABI version mismatch: library {lib.wt_abi_version()}, python {ABI_VERSION}")
     _lib = lib

@@ -50,11 +50,7 @@ class Builder:
         if model is None:
             logger.error("build_engine: no model was traced inside net_guard(network)")
             return None
-        half = builder_config.precision == "float16"
-        if half and not isinstance(model, WhisperEncoder):
-            logger.error("build_engine: float16 is implemented for the encoder engine only (fp16 encoder + fp32 decoder, "
-                         "BASELINE config 4); build the decoder with --engine_precision float32")
-            return None
+        half = builder_config.precision == "float16"   # both engines: build_encoder.py:25,62 / build_decoder.py:25,62, builder.py:55
         params = dict(network.named_parameters()) or dict(model.named_parameters())
         f32 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float32)
         val = lambda name: f32(params[name].value)
@@ -62,7 +58,7 @@ class Builder:
             if isinstance(model, WhisperEncoder):
                 blob = self._pack_encoder(model, val, f32, half)
             elif isinstance(model, WhisperDecoder):
-                blob = self._pack_decoder(model, val, f32)
+                blob = self._pack_decoder(model, val, f32, half)
             else:
                 logger.error(f"build_engine: unsupported model {type(model).__name__}")
                 return None
@@ -118,8 +114,19 @@ class Builder:
         t = scale * (wq64 @ beta.astype(np.float64) + bq.astype(np.float64))
         return tuple(np.ascontiguousarray(x, dtype=np.float32) for x in (w_fold, c, r, t))
 
-    def _pack_decoder(self, m: WhisperDecoder, val, f32) -> bytes:
+    def _pack_decoder(self, m: WhisperDecoder, val, f32, half: bool = False) -> bytes:
+        """`half` (--engine_precision float16, build_decoder.py:25,62): every GEMV weight matrix -- the self / cross projections, the FFN,
+        the folded cross query and the token table tied to the vocabulary projection -- is stored as IEEE half; biases, LayerNorm
+        parameters, embed_positions and the folded query's vectors stay fp32, and the kernels accumulate, normalise and soft-max in
+        fp32 (the reference forces fp32 scores in fp16 builds too, model.py:292-295).  The fold is formed in float64 from the ROUNDED
+        weights -- the fp16 model is the model whose weights are those fp16 values -- and rounded once more as a matrix."""
         d = m.d_model
+        if half:
+            if d % 8 or m.decoder_ffn_dim % 8:
+                raise ValueError("float16 decoder needs d_model and decoder_ffn_dim to be multiples of 8")
+            val32 = val
+            r16 = lambda a: a.astype(np.float16).astype(np.float32)
+            val = lambda name: r16(val32(name)) if name.endswith(".weight") and val32(name).ndim == 2 and not name.startswith("embed_positions") else val32(name)
         zeros = np.zeros((d,), np.float32)
         emb = val("embed_tokens.weight")
         proj = val("proj_out.weight")
@@ -148,4 +155,8 @@ class Builder:
         cfg = dict(d_model=d, n_heads=m.decoder_attention_heads, n_layers=len(m.layers), ffn_dim=m.decoder_ffn_dim,
                    n_mels=80, max_source_positions=m.max_source_positions, max_target_positions=m.max_target_positions,
                    vocab_size=m.vocab_size, tied_proj_out=int(tied))
-        return engine_pack.pack(engine_pack.KIND_DECODER, _dtypes.float32.code, cfg, t)
+        if half:
+            for name in list(t):
+                if name.endswith(".weight") and t[name].ndim == 2 and name != "embed_positions.weight":
+                    t[name] = t[name].astype(np.float16)
+        return engine_pack.pack(engine_pack.KIND_DECODER, (_dtypes.float16 if half else _dtypes.float32).code, cfg, t)

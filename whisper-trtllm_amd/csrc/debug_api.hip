@@ -127,3 +127,63 @@ extern "C" int wt_dbg_encoder_attention_f16(const void* qkv, void* ctx, int B, i
     return rc_of(launch_encoder_attention_f16(qkv, ctx, B, S, H, (hipStream_t)stream));
 }
 
+
+// ---- fp16 decoder engines: half weights (skinny GEMVs) and half K/V caches (decode attention); everything else fp32 ----
+extern "C" int wt_dbg_skinny_f16(const float* X, const float* ln_w, const float* ln_b, const void* W, const float* bias,
+                                 const float* resid, float* Y, int B, int N, int K, int xmode, int act, float scale, void* stream) {
+    SkinnyParams k;
+    memset(&k, 0, sizeof k);
+    k.X = X; k.ln_w = ln_w; k.ln_b = ln_b; k.W = (const float*)W; k.w_half = 1; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B; k.N = N; k.K = K;
+    k.xmode = xmode & 1; k.x_direct = (xmode >> 1) & 1; k.w_nt = (xmode >> 2) & 1; k.act = act; k.q_scale = scale; k.ymode = YMODE_PLAIN;
+    return rc_of(launch_skinny(k, (hipStream_t)stream));
+}
+extern "C" int wt_dbg_decode_attention_f16(const float* q, const void* kcache, const void* vcache, float* part, int* cnt, float* out,
+                                           const float* ln_h, const float* ln_r, const float* ln_t, int B, int H, int s_cap, int len,
+                                           int n_split, void* stream) {
+    if (len < 1 || len > s_cap || n_split < 1 || n_split > 16 || H * 64 > 1024) return -22;
+    if ((ln_h || ln_r || ln_t) && !(ln_h && ln_r && ln_t)) return -22;
+    DecAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.kcache = (const float*)kcache; a.vcache = (const float*)vcache; a.kv_half = 1; a.part = part; a.cnt = cnt; a.out = out;
+    a.B = B; a.H = H; a.s_cap = s_cap; a.n_split = n_split; a.fixed_len = len; a.nt = 1; a.ln_h = ln_h; a.ln_r = ln_r; a.ln_t = ln_t;
+    return rc_of(launch_dec_attn(a, (hipStream_t)stream));
+}
+extern "C" int wt_dbg_attention_then_projection_f16(const float* q, const void* kcache, const void* vcache, float* part, const void* W,
+                                                   const float* bias, const float* resid, float* Y, int B, int H, int s_cap, int len,
+                                                   void* stream) {
+    if (len < 1 || len > s_cap || H * 64 > 1024) return -22;
+    DecAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.kcache = (const float*)kcache; a.vcache = (const float*)vcache; a.kv_half = 1; a.part = part; a.B = B; a.H = H; a.s_cap = s_cap;
+    a.n_split = 2; a.fixed_len = len; a.nt = 1; a.defer_merge = 1;
+    int rc = rc_of(launch_dec_attn(a, (hipStream_t)stream));
+    if (rc) return rc;
+    SkinnyParams k;
+    memset(&k, 0, sizeof k);
+    k.parts = part; k.parts_nsplit = 2; k.parts_H = H; k.W = (const float*)W; k.w_half = 1; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B;
+    k.N = H * 64; k.K = H * 64; k.q_scale = 1.f; k.w_nt = 1;
+    return rc_of(launch_skinny(k, (hipStream_t)stream));
+}
+extern "C" int wt_dbg_skinny_pair_f16(const float* Xa, const void* Wa, const float* bias_a, const float* resid_a, float* Ya, int Na, int Ka,
+                                      const float* Xb, const float* Xb2, const void* Wb, const float* bias_b, float* Yb, int Nb, int Kb,
+                                      int B, void* stream) {
+    SkinnyParams a, b;
+    memset(&a, 0, sizeof a);
+    memset(&b, 0, sizeof b);
+    a.X = Xa; a.W = (const float*)Wa; a.w_half = 1; a.bias = bias_a; a.resid = resid_a; a.Y = Ya; a.B = B; a.N = Na; a.K = Ka; a.q_scale = 1.f; a.w_nt = 1;
+    b.X = Xb; b.X2 = Xb2; b.x_direct = 1; b.W = (const float*)Wb; b.w_half = 1; b.bias = bias_b; b.Y = Yb; b.B = B; b.N = Nb; b.K = Kb; b.q_scale = 1.f; b.w_nt = 1;
+    return rc_of(launch_skinny_pair(a, b, (hipStream_t)stream));
+}
+// cross-K/V projection of an fp16 decoder engine: A half [B][rows_total][d] (first `rows` rows of every utterance are projected),
+// W half [2d][d], bias f32 [2d] -> K / V caches [B][H][kv_cap][64] rows [seq_off, seq_off + rows), half (out_half) or f32
+extern "C" int wt_dbg_gemm_f16_kv(const void* A, int rows_total, const void* W, const float* bias, void* kcache, void* vcache, int B, int rows,
+                                  int H, int kv_cap, int seq_off, int out_half, void* stream) {
+    const int d = H * 64;
+    if (rows < 1 || rows > rows_total || seq_off < 0 || seq_off + rows > kv_cap) return -22;
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = (const float*)A; g.lda = d; g.a_rows_per_batch = rows; g.a_batch_stride = (long long)rows_total * d;
+    g.W = (const float*)W; g.bias = bias; g.M = B * rows; g.N = 2 * d; g.K = d;
+    g.epi = EPI_KV_HEADS; g.C = (float*)kcache; g.C2 = (float*)vcache; g.c_rows_per_batch = rows; g.kv_heads = H; g.kv_cap = kv_cap; g.kv_seq_off = seq_off;
+    return rc_of(launch_gemm_f16(g, out_half != 0, (hipStream_t)stream));
+}

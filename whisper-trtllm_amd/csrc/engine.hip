@@ -79,7 +79,10 @@ struct wt_engine {
     const float *tok_emb = nullptr, *pos_emb = nullptr, *proj_w = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
     int dec_cap = 0, dec_maxlen_cap = 0;
     char* dec_ws = nullptr;
-    float *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
+    float *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;  // resident caches: fp32, or IEEE half in fp16 engines
+    bool w_half = false;   // fp16 decoder engine: every GEMV weight matrix (incl. the tied vocabulary / token table) is IEEE half
+    int kv_esz = 4;        // bytes per element of the RESIDENT caches (2 in fp16 engines; Session-path caches are the caller's f32)
+    void* enc_h = nullptr; // fp16 engines: half copy of the encoder memory [B][S][d], the A operand of the cross-K/V projection
     float *dh = nullptr, *dh2 = nullptr, *dq = nullptr, *datt = nullptr, *dffn = nullptr, *part = nullptr, *logits = nullptr;
     int* att_cnt = nullptr;
     float* sel_val = nullptr;
@@ -221,8 +224,10 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         bool ok = it->second.ndim == (int)shape.size();
         for (int64_t s : shape) { ok = ok && it->second.shape[k] == s; ++k; }
         if (!ok && !g_err[0]) fail(WT_E_INVALID, "tensor '%s' has the wrong shape for this config", name.c_str());
-        // fp16 engines carry their GEMM operands (2-D *.weight) as fp16, everything else as fp32
-        const bool is_gemm_w = shape.size() == 2 && name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
+        // fp16 engines carry their GEMM / GEMV operands (2-D *.weight, incl. the token table tied to the vocabulary projection) as
+        // fp16, everything else (biases, LayerNorm parameters, position tables, the folded query's vectors) as fp32
+        const bool is_gemm_w = shape.size() == 2 && name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0 &&
+                               name != "embed_positions.weight";
         const int want = (e->precision == WT_F16 && is_gemm_w) ? WT_F16 : WT_F32;
         if (ok && it->second.dtype != want) {
             ok = false;
@@ -251,6 +256,8 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
             e->enc_layers.push_back(l);
         }
     } else {
+        e->w_half = e->precision == WT_F16;
+        e->kv_esz = e->w_half ? 2 : 4;
         e->tok_emb = need("embed_tokens.weight", {e->V, d});
         e->pos_emb = need("embed_positions.weight", {e->T, d});
         e->proj_w = hd.cfg[CFG_TIED] ? e->tok_emb : need("proj_out.weight", {e->V, d});
@@ -441,7 +448,8 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     const size_t d = e->d, kv_self = (size_t)e->L * B * e->H * e->T * HEAD_DIM, kv_cross = (size_t)e->L * B * e->H * e->S * HEAD_DIM;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_sk = take(kv_self * 4), o_sv = take(kv_self * 4), o_ck = take(kv_cross * 4), o_cv = take(kv_cross * 4);
+    const size_t o_sk = take(kv_self * e->kv_esz), o_sv = take(kv_self * e->kv_esz), o_ck = take(kv_cross * e->kv_esz), o_cv = take(kv_cross * e->kv_esz);
+    const size_t o_ench = take(e->w_half ? (size_t)B * e->S * d * 2 : 0);
     const size_t o_h = take((size_t)B * d * 4), o_h2 = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
     const size_t o_cnt = take((size_t)B * e->H * 4);
     const size_t o_selv = take((size_t)B * SEL_PARTS_CAP * 4), o_seli = take((size_t)B * SEL_PARTS_CAP * 4);
@@ -455,6 +463,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     e->dh = (float*)(b + o_h); e->dh2 = (float*)(b + o_h2); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->sel_val = (float*)(b + o_selv); e->sel_idx = (int*)(b + o_seli); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
     e->logits = (float*)(b + o_lg); e->st = (DecState*)(b + o_st); e->ids = (int*)(b + o_ids); e->unfinished = (int*)(b + o_unf);
     e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask);
+    e->enc_h = e->w_half ? (void*)(b + o_ench) : nullptr;
     HIPCHK(hipMemset(e->att_cnt, 0, (size_t)B * e->H * 4));  // arrival tickets start (and are left) at zero
     if (!e->h_state) HIPCHK(hipHostMalloc((void**)&e->h_state, sizeof(DecState), hipHostMallocDefault));
     if (!e->own_stream) {
@@ -479,8 +488,9 @@ static int pick_splits(int B, int H, int len) {
 // one decoder step over the resident (or caller-provided) caches; every step-dependent quantity comes from *st
 struct StepIO {
     const int* ids; int ids_ld;            // token fed to row b = ids[b*ids_ld + st->cur_len-1]
-    float *self_k, *self_v; int self_cap;  // layer stride = B*H*self_cap*64
-    float *cross_k, *cross_v;              // layer stride = B*H*S*64
+    float *self_k, *self_v; int self_cap;  // layer stride = B*H*self_cap*64 elements
+    float *cross_k, *cross_v;              // layer stride = B*H*S*64 elements
+    int kv_esz;                            // bytes per cache element: 4 (fp32; always on the Session path), 2 (resident caches of an fp16 engine)
     float* logits;                         // [B][V]
     int B, nsplit_self, nsplit_cross;
     bool embed;                            // launch the input-embedding kernel (the fast path gets it from greedy_finish)
@@ -497,10 +507,12 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     static const bool defer = tuning_env("WT_NO_DEFER_MERGE") == nullptr;  // A/B switch
     const int d = e->d, B = io.B, H = e->H;
     const DecLayerW& l = e->dec_layers[i];
-    float* sk = io.self_k + (size_t)i * B * H * io.self_cap * HEAD_DIM;
-    float* sv = io.self_v + (size_t)i * B * H * io.self_cap * HEAD_DIM;
-    const float* ck = io.cross_k + (size_t)i * B * H * e->S * HEAD_DIM;
-    const float* cv = io.cross_v + (size_t)i * B * H * e->S * HEAD_DIM;
+    const size_t self_layer = (size_t)i * B * H * io.self_cap * HEAD_DIM * io.kv_esz, cross_layer = (size_t)i * B * H * e->S * HEAD_DIM * io.kv_esz;
+    float* sk = (float*)((char*)io.self_k + self_layer);
+    float* sv = (float*)((char*)io.self_v + self_layer);
+    const float* ck = (const float*)((const char*)io.cross_k + cross_layer);
+    const float* cv = (const float*)((const char*)io.cross_v + cross_layer);
+    const int wh = e->w_half ? 1 : 0, kvh = io.kv_esz == 2 ? 1 : 0;
     SkinnyParams k, k2;
     DecAttnParams a;
     memset(&k, 0, sizeof k);
@@ -510,12 +522,12 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     case LP_QKV:  // self attention (model.py:273-281, 283-304): LN -> q|k|v, append k/v row in place
         k.X = h; k.ln_w = l.ln1_w; k.ln_b = l.ln1_b; k.xmode = XMODE_LAYERNORM; k.W = l.qkv_w; k.bias = l.qkv_b;
         k.Y = e->dq; k.kcache = sk; k.vcache = sv; k.st = e->st; k.B = B; k.N = 3 * d; k.K = d; k.ymode = YMODE_QKV_APPEND;
-        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = e->nt_loads;
+        k.d_model = d; k.s_cap = io.self_cap; k.q_scale = 0.125f; k.w_nt = e->nt_loads; k.w_half = wh; k.kv_half = kvh;
         LAUNCH(launch_skinny(k, s));
         break;
     case LP_SELF_ATTN:
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
-        a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads;
+        a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads; a.kv_half = kvh;
         a.defer_merge = defer && io.nsplit_self == 2;   // both halves of the pair launch below merge the two partials while staging
         LAUNCH(launch_dec_attn(a, s));
         break;
@@ -524,9 +536,9 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
         // u = s.Wq.diag(gamma2).(h + Wo.a + bo) = fold_w.[a ; h] + fold_c; LayerNorm statistics of h1 are applied
         // by the cross-attention kernel (model.py:261-272 semantics, one dependent launch fewer per layer)
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.o_w; k.bias = l.o_b; k.resid = h;
-        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
+        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads; k.w_half = wh;
         k2.X = e->datt; k2.X2 = h; k2.xmode = XMODE_PLAIN; k2.x_direct = 1; k2.W = l.fold_w; k2.bias = l.fold_c;
-        k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = e->nt_loads;
+        k2.Y = e->dq; k2.st = e->st; k2.B = B; k2.N = d; k2.K = 2 * d; k2.q_scale = 1.f; k2.w_nt = e->nt_loads; k2.w_half = wh;
         if (defer && io.nsplit_self == 2) {   // the self-attention context `a` arrives as two split partials per (utterance, head)
             k.parts = e->part; k.parts_nsplit = 2; k.parts_H = H;
             k2.parts = e->part; k2.parts_nsplit = 2; k2.parts_H = H;
@@ -535,7 +547,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
         break;
     case LP_CROSS_ATTN: {  // cross attention over the encoder memory: K/V already resident
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
-        a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t;
+        a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t; a.kv_half = kvh;
         a.defer_merge = defer && io.nsplit_cross == 2;  // the out-projection below merges the two split partials while staging them
                                                         // (more splits, i.e. batch < 8: the attention kernel merges its own, by ticket)
         hipEvent_t ta, tb;
@@ -546,18 +558,18 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     }
     case LP_CROSS_OUT:
         k.X = e->datt; k.xmode = XMODE_PLAIN; k.W = l.co_w; k.bias = l.co_b; k.resid = h1;
-        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
+        k.Y = h1; k.st = e->st; k.B = B; k.N = d; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads; k.w_half = wh;
         if (defer && io.nsplit_cross == 2) { k.parts = e->part; k.parts_nsplit = io.nsplit_cross; k.parts_H = H; }
         LAUNCH(launch_skinny(k, s));
         break;
     case LP_FC1:  // FFN (model.py:363-367)
         k.X = h1; k.ln_w = l.ln3_w; k.ln_b = l.ln3_b; k.xmode = XMODE_LAYERNORM; k.W = l.fc1_w; k.bias = l.fc1_b;
-        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = e->nt_loads;
+        k.Y = e->dffn; k.st = e->st; k.B = B; k.N = e->F; k.K = d; k.act = 1; k.q_scale = 1.f; k.w_nt = e->nt_loads; k.w_half = wh;
         LAUNCH(launch_skinny(k, s));
         break;
     case LP_FC2:
         k.X = e->dffn; k.xmode = XMODE_PLAIN; k.W = l.fc2_w; k.bias = l.fc2_b; k.resid = h1; k.Y = h1; k.st = e->st;
-        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = e->nt_loads;
+        k.B = B; k.N = d; k.K = e->F; k.q_scale = 1.f; k.w_nt = e->nt_loads; k.w_half = wh;
         LAUNCH(launch_skinny(k, s));
         break;
     default:
@@ -568,7 +580,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
 
 static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
     const int d = e->d, B = io.B;
-    if (io.embed) LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s));
+    if (io.embed) LAUNCH(launch_dec_embed(io.ids, io.ids_ld, e->tok_emb, e->pos_emb, e->dh, B, d, e->st, s, e->w_half));
     SkinnyParams k;
     // The residual stream ping-pongs between two buffers once per layer: the self-attention out-projection (h1 = h + Wo.a)
     // and the folded cross-attention query (which still reads h) share one launch, so h1 cannot overwrite h in place.
@@ -583,7 +595,7 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
     // final LN + vocabulary projection (model.py:455-457; logits are the engine's 'hidden_states' output)
     memset(&k, 0, sizeof k);
     k.X = h; k.ln_w = e->dec_ln_w; k.ln_b = e->dec_ln_b; k.xmode = XMODE_LAYERNORM; k.W = e->proj_w; k.Y = io.logits;
-    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads;
+    k.st = e->st; k.B = B; k.N = e->V; k.K = d; k.q_scale = 1.f; k.w_nt = e->nt_loads; k.w_half = e->w_half;
     if (io.argmax) {  // Suppress -> SuppressAtBegin -> argmax in the epilogue (Force / pad / EOS rules: greedy_finish_kernel)
         const SelectParams& sp = *io.argmax;
         k.ymode = YMODE_ARGMAX; k.Y = nullptr; k.am_mask = sp.mask; k.am_val = sp.part_val; k.am_idx = sp.part_idx;
@@ -602,20 +614,30 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
     return WT_OK;
 }
 
-static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int rows, int seq_off, float* ck, float* cv,
+static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int rows, int seq_off, float* ck, float* cv, int kv_esz,
                             hipStream_t s) {
-    // K/V projection of encoder rows [0, rows) of every utterance into cache rows [seq_off, seq_off+rows)
+    // K/V projection of encoder rows [0, rows) of every utterance into cache rows [seq_off, seq_off+rows).  fp16 engines: the encoder
+    // memory is rounded to fp16 once (the MFMA's A operand), the product accumulates in fp32 and lands in the caches as `kv_esz` says.
     const int d = e->d;
+    if (e->w_half) LAUNCH(launch_cast_h(enc_hidden, e->enc_h, (size_t)B * e->S * d, s));
     for (int i = 0; i < e->L; ++i) {
         const DecLayerW& l = e->dec_layers[i];
+        const size_t layer = (size_t)i * B * e->H * e->S * HEAD_DIM * kv_esz;
         GemmParams g;
         memset(&g, 0, sizeof g);
-        g.A = enc_hidden; g.lda = d; g.a_rows_per_batch = rows; g.a_batch_stride = (long long)e->S * d;
+        g.A = e->w_half ? (const float*)e->enc_h : enc_hidden; g.lda = d; g.a_rows_per_batch = rows; g.a_batch_stride = (long long)e->S * d;
         g.W = l.ckv_w; g.bias = l.ckv_b; g.M = B * rows; g.N = 2 * d; g.K = d;
-        g.epi = EPI_KV_HEADS; g.C = ck + (size_t)i * B * e->H * e->S * HEAD_DIM; g.C2 = cv + (size_t)i * B * e->H * e->S * HEAD_DIM;
+        g.epi = EPI_KV_HEADS; g.C = (float*)((char*)ck + layer); g.C2 = (float*)((char*)cv + layer);
         g.c_rows_per_batch = rows; g.kv_heads = e->H; g.kv_cap = e->S; g.kv_seq_off = seq_off;
-        int rc = timed_gemm(e, g, s);
-        if (rc) return rc;
+        if (e->w_half) {
+            hipEvent_t ta, tb;
+            timer_begin(e, e->t_gemm, s, &ta, &tb);
+            LAUNCH(launch_gemm_f16(g, kv_esz == 2, s));
+            timer_end(e, e->t_gemm, s, ta, tb);
+        } else {
+            int rc = timed_gemm(e, g, s);
+            if (rc) return rc;
+        }
     }
     return WT_OK;
 }
@@ -673,7 +695,7 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         // Measured ms per step, non-temporal vs default: tiny.en B=1 (136 MB) 0.171 vs 0.160; tiny.en B=8 (300 MB) 0.224 vs 0.221;
         // base.en B=8 0.324 vs 0.340; small.en B=8 0.688 vs 0.711; medium.en B=8 1.61 vs 1.66.
         const double p_step = (double)e->L * (6.0 * e->d * e->d + 2.0 * e->d * e->F) + (double)e->V * e->d;
-        const double step_bytes = 4.0 * p_step + (double)B * 2.0 * e->L * e->H * ((double)e->S + p->max_length) * HEAD_DIM * 4.0;
+        const double step_bytes = (e->w_half ? 2.0 : 4.0) * p_step + (double)B * 2.0 * e->L * e->H * ((double)e->S + p->max_length) * HEAD_DIM * e->kv_esz;
         const int nt = step_bytes > 160e6;
         if (nt != e->nt_loads) e->graph_valid = false;
         e->nt_loads = nt;
@@ -690,8 +712,8 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     }
     e->nsplit_cross = tuning_env("WT_NSPLIT_CROSS") ? atoi(tuning_env("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
-    LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s));  // input of step 0
-    rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, s);
+    LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s, e->w_half));  // input of step 0
+    rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, e->kv_esz, s);
     if (rc) return rc;
     e->begun = true;
     return WT_OK;
@@ -700,7 +722,7 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
 static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     StepIO io;
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
-    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
+    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
     io.embed = false;  // dh already holds this step's input: written by wt_decoder_begin (step 0) or by the previous greedy_finish
     static const bool fuse = tuning_env("WT_NO_FUSED_ARGMAX") == nullptr;  // A/B switch: logits to HBM + greedy_select_kernel
@@ -710,7 +732,7 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     sp.st = e->st; sp.trace = e->trace; sp.B = e->B; sp.V = e->V; sp.max_length = e->max_length;
     sp.begin_index = e->begin_index; sp.eos = e->eos; sp.pad = e->pad; sp.force_eos_step = e->force_eos_step;
     sp.part_val = e->sel_val; sp.part_idx = e->sel_idx; sp.tok_emb = e->tok_emb; sp.pos_emb = e->pos_emb; sp.next_x = e->dh;
-    sp.d_model = e->d; sp.n_parts = 8; sp.fused = 0;
+    sp.d_model = e->d; sp.n_parts = 8; sp.fused = 0; sp.emb_half = e->w_half;
     int parts = 0;
     io.argmax = fuse ? &sp : nullptr;
     io.argmax_parts = &parts;
@@ -852,13 +874,13 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     LAUNCH(launch_copy_cache_rows(cpk, nck, LH, S, S, cross_len, s));
     LAUNCH(launch_copy_cache_rows(cpv, ncv, LH, S, S, cross_len, s));
     if (cross_len < S) {  // cur = proj(enc[0 : S - cross_len]) lands behind the kept rows (model.py:265-272)
-        rc = cross_kv_project(e, enc, 1, S - cross_len, cross_len, nck, ncv, s);
+        rc = cross_kv_project(e, enc, 1, S - cross_len, cross_len, nck, ncv, 4, s);   // Session I/O caches are f32 in every engine (model.py:464-468)
         if (rc) return rc;
     }
     LAUNCH(launch_set_state(e->st, /*cur_len=*/1, /*pos=*/e->c_ms - 1, /*self_len=*/cache_len, s));
     StepIO io;
     io.ids = data; io.ids_ld = 1; io.self_k = nsk; io.self_v = nsv; io.self_cap = cache_len + 1;
-    io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1;
+    io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1; io.kv_esz = 4;
     io.nsplit_self = 1; io.nsplit_cross = pick_splits(1, e->H, S);
     io.embed = true;
     io.argmax = nullptr; io.argmax_parts = nullptr;
@@ -915,7 +937,7 @@ extern "C" int wt_decoder_time_kernel(wt_engine* e, const char* which, int iters
     hipStream_t s = (hipStream_t)stream;
     StepIO io;
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
-    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B;
+    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross; io.embed = false; io.argmax = nullptr; io.argmax_parts = nullptr;
     struct ProfilingOff {   // no event records inside the capture; the caller's setting comes back on every exit path
         wt_engine* e; bool was;

@@ -43,8 +43,8 @@ int parse_blob(const void* blob, size_t nbytes, ParsedBlob* out, char* err, size
         return fail(err, errlen, WT_E_INVALID, "engine blob is truncated or corrupt (header says %llu bytes, got %zu)",
                     (unsigned long long)hd.total_bytes, nbytes);
     if (hd.kind != WT_KIND_ENCODER && hd.kind != WT_KIND_DECODER) return fail(err, errlen, WT_E_INVALID, "unknown engine kind %u", hd.kind);
-    if (hd.precision != WT_F32 && !(hd.precision == WT_F16 && hd.kind == WT_KIND_ENCODER))
-        return fail(err, errlen, WT_E_UNSUPPORTED, "engine precision %u: float32, or float16 for the encoder engine only", hd.precision);
+    if (hd.precision != WT_F32 && hd.precision != WT_F16)
+        return fail(err, errlen, WT_E_UNSUPPORTED, "engine precision %u: float32 or float16 (builder.py:55)", hd.precision);
 
     EngineDims& e = out->dims;
     e.kind = (int)hd.kind;
@@ -61,8 +61,10 @@ int parse_blob(const void* blob, size_t nbytes, ParsedBlob* out, char* err, size
     if (e.L <= 0 || e.L > 64 || e.F <= 0 || (e.F & 3) || e.F > 4096) return bad("ffn_dim must be a multiple of 4 and <= 4096, 1..64 layers");
     if (e.S <= 0 || e.S > 4096 || e.C <= 0 || e.C > 128 || (e.C & 3)) return bad("num_mel_bins must be a multiple of 4 and <= 128, max_source_positions <= 4096");
     if (e.kind == WT_KIND_DECODER && (e.T <= 1 || e.T > 4096 || e.V <= 0 || e.V > (1 << 20))) return bad("decoder needs max_target_positions in 2..4096 and a vocabulary");
-    if (e.precision == WT_F16 && ((e.C & 7) || (e.d & 7) || (e.F & 7) || e.F < e.d))
+    if (e.precision == WT_F16 && e.kind == WT_KIND_ENCODER && ((e.C & 7) || (e.d & 7) || (e.F & 7) || e.F < e.d))
         return bad("float16 encoder needs num_mel_bins, d_model, ffn_dim multiples of 8 and ffn_dim >= d_model (workspace layout)");
+    if (e.precision == WT_F16 && e.kind == WT_KIND_DECODER && ((e.d & 7) || (e.F & 7)))
+        return bad("float16 decoder needs d_model and ffn_dim to be multiples of 8 (eight halves per 16-byte weight load)");
 
     const char* base = (const char*)blob;
     out->tensors.reserve(hd.n_tensors);

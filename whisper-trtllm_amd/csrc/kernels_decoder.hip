@@ -11,6 +11,7 @@
 // :306-369 (WhisperDecoderLayer), :407-470 (WhisperDecoder.forward); greedy loop examples/whisper/run.py:171-227;
 // processors HF generation/logits_process.py:1281-1328.  Numerics follow the HF oracle.
 #include "wt_common.h"
+#include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -40,23 +41,29 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 
 // ------------------------------------------------------------------------------------------------ embed
 // x[b] = embed_tokens[ids[b][cur_len-1]] + embed_positions[pos]      (model.py:423-425; HF :1149-1156)
+// fp16 decoder engines keep embed_tokens (tied to the vocabulary projection) in fp16; embed_positions stays fp32.
+__device__ __forceinline__ float4 load_emb4(const float* tab, size_t elem, const bool half) {
+    if (!half) return *reinterpret_cast<const float4*>(tab + elem);
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(tab) + elem);
+    const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x)), b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
 __global__ __launch_bounds__(256) void dec_embed_kernel(const int* __restrict__ ids, int ids_ld,
                                                         const float* __restrict__ tok_emb,
                                                         const float* __restrict__ pos_emb, float* __restrict__ x, int d,
-                                                        const DecState* __restrict__ st) {
+                                                        const DecState* __restrict__ st, int emb_half) {
     const int b = blockIdx.x;
     const int tok = ids[(size_t)b * ids_ld + st->cur_len - 1];
-    const float4* te = reinterpret_cast<const float4*>(tok_emb + (size_t)tok * d);
     const float4* pe = reinterpret_cast<const float4*>(pos_emb + (size_t)st->pos * d);
     float4* xo = reinterpret_cast<float4*>(x + (size_t)b * d);
     for (int i = threadIdx.x; i < (d >> 2); i += 256) {
-        float4 a = te[i], c = pe[i];
+        const float4 a = load_emb4(tok_emb, (size_t)tok * d + 4 * i, emb_half != 0), c = pe[i];
         xo[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
     }
 }
 hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
-                            int d, const DecState* st, hipStream_t s) {
-    hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(256), 0, s, ids, ids_ld, tok_emb, pos_emb, x, d, st);
+                            int d, const DecState* st, hipStream_t s, int emb_half) {
+    hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(256), 0, s, ids, ids_ld, tok_emb, pos_emb, x, d, st, emb_half);
     return hipGetLastError();
 }
 
@@ -69,7 +76,12 @@ hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, co
 // each (row, batch) total in one lane, which applies the epilogue.  When K exceeds a slice, the NW waves of a block
 // split K (nsplit = 2, 4 or 8) and combine through LDS.  Whole activation rows (K <= 1024) are staged -- and
 // LayerNorm-ed -- once per block through LDS.
-template <int NB, int V, int NW, bool W_NT, bool HALF = false, bool ARGMAX = false>
+// WH (fp16 decoder engines, build_decoder.py --engine_precision float16): W is IEEE half, everything else (activations, accumulation,
+// LayerNorm, epilogue) stays fp32.  A lane's 16-byte load then carries EIGHT columns, so the slice chunk map becomes
+// column(v) = ks0 + 8*lane + 512*(v>>1) + 4*(v&1): the same 256*V columns per wave, the same activation registers and the same K-split
+// plan as the fp32 form, half the weight bytes per row (V/2 loads of 1 KiB per wave and row); the halves are widened with
+// v_cvt_f32_f16 right before the packed FMAs.
+template <int NB, int V, int NW, bool W_NT, bool HALF = false, bool ARGMAX = false, bool WH = false>
 __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsplit, const int KS, const int rows_per_group,
                                             const int block) {
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
@@ -84,31 +96,46 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     const int row_begin = (int)min((long long)p.N, group_id * rows_per_group);
     const int row_end = min(p.N, row_begin + rows_per_group);
 
+    static_assert(!WH || (V % 2) == 0, "half weights: two activation chunks per 16-byte load");
+    constexpr int VW = WH ? V / 2 : V;             // 16-byte weight loads per row and lane
+    constexpr int WSZ = WH ? 2 : 4;                // bytes per weight element
+    auto colu = [&](const int v) { return WH ? ks0 + 8 * lane + 512 * (v >> 1) + 4 * (v & 1) : ks0 + 4 * lane + 256 * v; };
     float4 xr[NB][V];
     bool kok[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) kok[v] = (ks0 + 4 * lane + 256 * v) < kend;
+    for (int v = 0; v < V; ++v) kok[v] = colu(v) < kend;
     // ---- stream W ----------------------------------------------------------------------------------------------
     // Every load below is UNCONDITIONAL from a clamped address, with out-of-range lanes zeroed afterwards: a predicated
     // load (`ok ? *p : 0`) compiles to an exec-masked branch whose merge copy makes the compiler wait for vmcnt(0) in the
     // middle of the request burst -- one full HBM round trip before the remaining loads are even issued.
-    int kcol[V];   // this lane's column of slice chunk v, clamped into the slice
+    int kcol[V];   // this lane's column of slice chunk v, clamped into the slice (half weights: the 8-column load is clamped as a whole)
 #pragma unroll
-    for (int v = 0; v < V; ++v) kcol[v] = min(ks0 + 4 * lane + 256 * v, kend - 4);
-    float4 wbuf[2][2][V];
+    for (int v = 0; v < V; ++v) kcol[v] = WH ? min(ks0 + 8 * lane + 512 * (v >> 1), kend - 8) + 4 * (v & 1) : min(colu(v), kend - 4);
+    typedef float f4v __attribute__((ext_vector_type(4)));   // 16 raw bytes: four floats, or eight halves
+    f4v wbuf[2][2][VW];
     auto wload = [&](int buf, int row) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const float* wp = p.W + (size_t)min(row + r, p.N - 1) * p.K;
+            const char* wp = reinterpret_cast<const char*>(p.W) + (size_t)min(row + r, p.N - 1) * p.K * WSZ;
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                if (W_NT) {  // weights are read exactly once per step: non-temporal (streaming) loads
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(wp + kcol[v]));
-                    wbuf[buf][r][v] = make_float4(t[0], t[1], t[2], t[3]);
-                } else
-                    wbuf[buf][r][v] = *reinterpret_cast<const float4*>(wp + kcol[v]);
+            for (int c = 0; c < VW; ++c) {
+                const f4v* src = reinterpret_cast<const f4v*>(wp + (size_t)kcol[WH ? 2 * c : c] * WSZ);
+                if (W_NT) wbuf[buf][r][c] = __builtin_nontemporal_load(src);  // weights are read exactly once per step: streaming loads
+                else wbuf[buf][r][c] = *src;
             }
+        }
+    };
+    auto wget = [&](const int buf, const int r, const int v) -> float4 {   // the four weights that meet activation chunk v
+        if constexpr (WH) {
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+            const f4v raw = wbuf[buf][r][v >> 1];
+            // (copies first: __builtin_bit_cast applied directly to a vector-element expression `raw[i]` reads element 0 with this clang)
+            const float f0 = raw[2 * (v & 1)], f1 = raw[2 * (v & 1) + 1];
+            const h2v lo = __builtin_bit_cast(h2v, f0), hi = __builtin_bit_cast(h2v, f1);
+            return make_float4((float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]);
+        } else {
+            const f4v raw = wbuf[buf][r][v];
+            return make_float4(raw[0], raw[1], raw[2], raw[3]);
         }
     };
     // W values of clamped (out-of-slice) lanes are multiplied by activations that ARE zeroed below, so they need no fix-up
@@ -261,7 +288,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int v = 0; v < V; ++v)
-                    xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][ks0 + 4 * lane + 256 * v]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xr[b][v] = kok[v] ? *reinterpret_cast<const float4*>(&xs[b][colu(v)]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
         if (p.X2 == nullptr) {  // rows longer than the staging buffer (or x_direct): each wave loads its own K-slice straight from L2
@@ -326,7 +353,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                     f2v a2 = f2v{0.f, 0.f};
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        const float4 w = wbuf[cur][r][v];
+                        const float4 w = wget(cur, r, v);
                         a2 = __builtin_elementwise_fma(f2v{w.x, w.y}, f2v{xr[b][v].x, xr[b][v].y}, a2);
                         a2 = __builtin_elementwise_fma(f2v{w.z, w.w}, f2v{xr[b][v].z, xr[b][v].w}, a2);
                     }
@@ -389,7 +416,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
                 } else {
                     const int h = nn >> 6, j = nn & 63, H = p.d_model >> 6;
                     float* cache = third == 1 ? p.kcache : p.vcache;
-                    cache[(((size_t)my_b * H + h) * p.s_cap + self_len_pf) * HEAD_DIM + j] = v;
+                    const size_t at = (((size_t)my_b * H + h) * p.s_cap + self_len_pf) * HEAD_DIM + j;
+                    if (p.kv_half) reinterpret_cast<__half*>(cache)[at] = __float2half(v);   // fp16 engines: resident caches in fp16
+                    else cache[at] = v;
                 }
             }
         }
@@ -430,19 +459,19 @@ struct SkinnyPlan {
     int nsplit, KS, rows_per_group, grid;
 };
 
-template <int NB, int V, int NW, bool W_NT, bool ARGMAX = false>
+template <int NB, int V, int NW, bool W_NT, bool ARGMAX = false, bool WH = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(const SkinnyParams p, const int nsplit, const int KS,
                                                                              const int rows_per_group) {
-    skinny_body<NB, V, NW, W_NT, false, ARGMAX>(p, nsplit, KS, rows_per_group, blockIdx.x);
+    skinny_body<NB, V, NW, W_NT, false, ARGMAX, WH>(p, nsplit, KS, rows_per_group, blockIdx.x);
 }
 
 // Two GEMMs that depend on the same predecessor share ONE launch (the self-attention out-projection and the folded
 // cross-attention query): blocks [0, pa.grid) run `a`, the rest run `b`.  The branch is block-uniform.
-template <int NB, int V, int NW, bool HALF_B>
+template <int NB, int V, int NW, bool HALF_B, bool WH = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_pair_kernel(const SkinnyParams a, const SkinnyPlan pa,
                                                                              const SkinnyParams b, const SkinnyPlan pb) {
-    if ((int)blockIdx.x < pa.grid) skinny_body<NB, V, NW, true>(a, pa.nsplit, pa.KS, pa.rows_per_group, blockIdx.x);
-    else skinny_body<NB, V, NW, true, HALF_B>(b, pb.nsplit, pb.KS, pb.rows_per_group, blockIdx.x - pa.grid);
+    if ((int)blockIdx.x < pa.grid) skinny_body<NB, V, NW, true, false, false, WH>(a, pa.nsplit, pa.KS, pa.rows_per_group, blockIdx.x);
+    else skinny_body<NB, V, NW, true, HALF_B, false, WH>(b, pb.nsplit, pb.KS, pb.rows_per_group, blockIdx.x - pa.grid);
 }
 
 template <int NB, int V, int NW>
@@ -455,6 +484,7 @@ static hipError_t skinny_plan(const SkinnyParams& p, SkinnyPlan* out, int tg_ove
     }
     const int KS = p.K / nsplit;
     if (KS & 3) return hipErrorInvalidValue;
+    if (p.w_half && ((KS & 7) || (reinterpret_cast<uintptr_t>(p.W) & 15))) return hipErrorInvalidValue;   // eight halves per 16-byte load
     if (p.K > 1024 && p.xmode != XMODE_PLAIN) return hipErrorInvalidValue;  // LayerNorm needs whole rows staged in LDS
     if (p.X2 && (p.xmode != XMODE_PLAIN || (p.K & 7))) return hipErrorInvalidValue;
     if (p.parts && !p.X2 && (p.K > 1024 || p.K != p.parts_H * 64 || p.parts_nsplit != 2)) return hipErrorInvalidValue;
@@ -484,7 +514,13 @@ static hipError_t skinny_smem_attr() {
                               reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true, true>),
                               reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false, true>),
                               reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, false>),
-                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, true>)}) {
+                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, true>),
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true, false, true>),
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false, false, true>),
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, true, true, true>),
+                              reinterpret_cast<const void*>(skinny_gemm_kernel<NB, V, NW, false, true, true>),
+                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, false, true>),
+                              reinterpret_cast<const void*>(skinny_pair_kernel<NB, V, NW, true, true>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return e;
         }
@@ -500,11 +536,20 @@ static hipError_t skinny_launch_cfg(const SkinnyParams& p, hipStream_t s) {
     if (e == hipSuccess) e = skinny_smem_attr<NB, V, NW>();
     if (e != hipSuccess) return e;
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
-    if (p.ymode == YMODE_ARGMAX) {
-        if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
-    } else if (p.w_nt) hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, true>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, false>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
+#define WT_SK_LAUNCH(NT_, AM_, WH_) \
+    hipLaunchKernelGGL((skinny_gemm_kernel<NB, V, NW, NT_, AM_, WH_>), dim3(pl.grid), dim3(64 * NW), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group)
+    const int sel = (p.ymode == YMODE_ARGMAX ? 4 : 0) | (p.w_nt ? 2 : 0) | (p.w_half ? 1 : 0);
+    switch (sel) {
+    case 0: WT_SK_LAUNCH(false, false, false); break;
+    case 1: WT_SK_LAUNCH(false, false, true); break;
+    case 2: WT_SK_LAUNCH(true, false, false); break;
+    case 3: WT_SK_LAUNCH(true, false, true); break;
+    case 4: WT_SK_LAUNCH(false, true, false); break;
+    case 5: WT_SK_LAUNCH(false, true, true); break;
+    case 6: WT_SK_LAUNCH(true, true, false); break;
+    default: WT_SK_LAUNCH(true, true, true); break;
+    }
+#undef WT_SK_LAUNCH
     return hipGetLastError();
 }
 
@@ -525,8 +570,15 @@ static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, 
     if (e != hipSuccess) return e;
     constexpr int smem = (NB * 1024 + 2 * NW * 2 * NB) * (int)sizeof(float);
     if (a.parts && a.X2) return hipErrorInvalidValue;   // the half-staged form exists for the second GEMV of a pair only
-    if (b.parts && b.X2) hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, true>), dim3(pa.grid + pb.grid), dim3(64 * NW), smem, s, a, pa, b, pb);
-    else hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, false>), dim3(pa.grid + pb.grid), dim3(64 * NW), smem, s, a, pa, b, pb);
+    if (a.w_half != b.w_half) return hipErrorInvalidValue;
+    const dim3 grid(pa.grid + pb.grid), blk(64 * NW);
+    if (a.w_half) {
+        if (b.parts && b.X2) hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, true, true>), grid, blk, smem, s, a, pa, b, pb);
+        else hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, false, true>), grid, blk, smem, s, a, pa, b, pb);
+    } else {
+        if (b.parts && b.X2) hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, true>), grid, blk, smem, s, a, pa, b, pb);
+        else hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, false>), grid, blk, smem, s, a, pa, b, pb);
+    }
     return hipGetLastError();
 }
 
@@ -556,55 +608,89 @@ hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipS
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention
-// One query row per (utterance, head); keys/values [S][64] fp32 streamed once.  Grid (n_split, H, B); a block's
-// 4 waves x 4 sixteen-lane rows form 16 independent online-softmax streams over interleaved keys (each
-// 16-lane row reads one 256-byte key per load, 4 keys = 1 KiB per wave instruction); the 16 stream states are
-// merged through LDS into one partial (o[64] unnormalised, m, l) per split.  With n_split > 1 the splits of a
-// (utterance, head) are merged by whichever block arrives last (arrival ticket; partials stored write-through
-// and re-read with sc1 loads, cdna guide §6 G16 R1); the merge walks the partials in split order, so the result is bitwise reproducible
-// whatever the arrival order.  Output: normalised context rows out[b][h*64 .. +63].
-template <int U, bool NT>
+// One query row per (utterance, head); keys/values [S][64] streamed once.  Grid (n_split, H, B).  A key is read by a group of LPK
+// lanes with one 16-byte load each: fp32 caches 16 lanes x 4 dims (a block's 4 waves form 16 independent online-softmax streams),
+// fp16 caches (fp16 decoder engines) 8 lanes x 8 dims (32 streams) -- either way one wave instruction reads 1 KiB of consecutive
+// keys.  Streams take interleaved keys; their states are merged through LDS into one partial (o[64] unnormalised, m, l) per split.
+// With n_split > 1 the splits of a (utterance, head) are merged by whichever block arrives last (arrival ticket; partials stored
+// write-through and re-read with sc1 loads, cdna guide §6 G16 R1); the merge walks the partials in split order, so the result is
+// bitwise reproducible whatever the arrival order.  Scores, softmax and accumulators are fp32 in both forms (the reference forces
+// fp32 scores in fp16 builds too, model.py:292-295).  Output: normalised context rows out[b][h*64 .. +63].
+__device__ __forceinline__ float row8_allreduce_sum(float v) {   // sum over each aligned group of 8 lanes, total in every lane
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xf, 0xf, false));  // row_half_mirror: i <-> 7-i
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    return v;
+}
+template <int U, bool NT, bool KVH>
 __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
-    __shared__ float sm_o[16][HEAD_DIM];
-    __shared__ float sm_m[16], sm_l[16];
+    constexpr int LPK = KVH ? 8 : 16;          // lanes per key
+    constexpr int DPL = HEAD_DIM / LPK;        // head dims per lane: 8 or 4 (16 bytes of K or V either way)
+    constexpr int NSTR = 256 / LPK;            // online-softmax streams per block
+    constexpr int KSZ = KVH ? 2 : 4;
+    __shared__ float sm_o[NSTR][HEAD_DIM];
+    __shared__ float sm_m[NSTR], sm_l[NSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, sid = wave * 4 + (lane >> 4);
+    const int c = lane & (LPK - 1), sid = tid / LPK;
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int len = p.fixed_len > 0 ? p.fixed_len : p.st->self_len + 1;
     const int chunk = (len + p.n_split - 1) / p.n_split;
     const int s_begin = split * chunk, s_end = min(len, s_begin + chunk);
     const int d = p.H * HEAD_DIM;
 
-    const float* kb = p.kcache + ((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + 4 * c;
-    const float* vb = p.vcache + ((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + 4 * c;
-
-    auto load_tile = [&](float4 (&kk)[U], float4 (&vv)[U], const int s0) {
+    const char* kb = reinterpret_cast<const char*>(p.kcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
+    const char* vb = reinterpret_cast<const char*>(p.vcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
+    typedef float f4v __attribute__((ext_vector_type(4)));   // 16 raw bytes
+    auto load_tile = [&](f4v (&kk)[U], f4v (&vv)[U], const int s0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = min(s0 + 16 * u, s_end - 1);
+            const size_t key = (size_t)min(s0 + NSTR * u, s_end - 1) * (HEAD_DIM * KSZ);
             if (NT) {  // K/V are read exactly once per step: non-temporal loads keep them from displacing weights in L2
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v a = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(kb + (size_t)key * HEAD_DIM));
-                const f4v c2 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vb + (size_t)key * HEAD_DIM));
-                kk[u] = make_float4(a[0], a[1], a[2], a[3]);
-                vv[u] = make_float4(c2[0], c2[1], c2[2], c2[3]);
+                kk[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(kb + key));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vb + key));
             } else {
-                kk[u] = *reinterpret_cast<const float4*>(kb + (size_t)key * HEAD_DIM);
-                vv[u] = *reinterpret_cast<const float4*>(vb + (size_t)key * HEAD_DIM);
+                kk[u] = *reinterpret_cast<const f4v*>(kb + key);
+                vv[u] = *reinterpret_cast<const f4v*>(vb + key);
             }
+        }
+    };
+    auto widen = [&](const f4v raw, float (&x)[DPL]) {
+        if constexpr (KVH) {
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float f = raw[i];   // (a copy first: __builtin_bit_cast of the element expression itself reads element 0)
+                const h2v t = __builtin_bit_cast(h2v, f);
+                x[2 * i] = (float)t[0];
+                x[2 * i + 1] = (float)t[1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = raw[i];
         }
     };
     // the first K/V tile is requested before the query prologue, whose loads and reductions then hide under its latency
     const int s_first = s_begin + sid;
-    float4 kk[U], vv[U];
+    f4v kk[U], vv[U];
     if (s_first < s_end) load_tile(kk, vv, s_first);
 
-    float4 q = *reinterpret_cast<const float4*>(p.q + (size_t)b * d + h * HEAD_DIM + 4 * c);
+    float q[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p.q + (size_t)b * d + h * HEAD_DIM + DPL * c + i);
+        q[i] = t.x; q[i + 1] = t.y; q[i + 2] = t.z; q[i + 3] = t.w;
+    }
     if (p.ln_h) {
         // folded query: finish the LayerNorm of the residual row here (every wave for itself: d <= 1024 floats, no barrier),
         // two-pass statistics like the LayerNorm kernels: q = (u - mean . r) * rstd + t
-        const float4 r4 = *reinterpret_cast<const float4*>(p.ln_r + h * HEAD_DIM + 4 * c);
-        const float4 t4 = *reinterpret_cast<const float4*>(p.ln_t + h * HEAD_DIM + 4 * c);
+        float r[DPL], t[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; i += 4) {
+            const float4 r4 = *reinterpret_cast<const float4*>(p.ln_r + h * HEAD_DIM + DPL * c + i);
+            const float4 t4 = *reinterpret_cast<const float4*>(p.ln_t + h * HEAD_DIM + DPL * c + i);
+            r[i] = r4.x; r[i + 1] = r4.y; r[i + 2] = r4.z; r[i + 3] = r4.w;
+            t[i] = t4.x; t[i + 1] = t4.y; t[i + 2] = t4.z; t[i + 3] = t4.w;
+        }
         const float* hr = p.ln_h + (size_t)b * d;
         float4 hv[4];
 #pragma unroll
@@ -626,39 +712,46 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
                 sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
         const float rstd = rsqrtf(wave_allreduce_sum_d(sq) / d + 1e-5f);
-        q.x = (q.x - mean * r4.x) * rstd + t4.x;
-        q.y = (q.y - mean * r4.y) * rstd + t4.y;
-        q.z = (q.z - mean * r4.z) * rstd + t4.z;
-        q.w = (q.w - mean * r4.w) * rstd + t4.w;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) q[i] = (q[i] - mean * r[i]) * rstd + t[i];
     }
     float m = -INFINITY, l = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = s_first; s0 < s_end; s0 += 16 * U) {  // (a register double buffer of the tiles measured 0.5-1 us SLOWER per launch)
+    float acc[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+    for (int s0 = s_first; s0 < s_end; s0 += NSTR * U) {  // (a register double buffer of the tiles measured 0.5-1 us SLOWER per launch)
         if (s0 != s_first) load_tile(kk, vv, s0);
         float sc[U];
         float mx = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            sc[u] = row16_allreduce_sum(dot4(q, kk[u]));
-            if (s0 + 16 * u >= s_end) sc[u] = -INFINITY;
+            float kf[DPL];
+            widen(kk[u], kf);
+            float dot = q[DPL - 1] * kf[DPL - 1];
+#pragma unroll
+            for (int i = DPL - 2; i >= 0; --i) dot = fmaf(q[i], kf[i], dot);
+            sc[u] = KVH ? row8_allreduce_sum(dot) : row16_allreduce_sum(dot);
+            if (s0 + NSTR * u >= s_end) sc[u] = -INFINITY;
             mx = fmaxf(mx, sc[u]);
         }
         // s0 < s_end, so u = 0 is always a real key and mx is finite here
         const float alpha = __expf(m - mx);
         l *= alpha;
-        acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] *= alpha;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float pr = __expf(sc[u] - mx);
             l += pr;
-            acc.x = fmaf(pr, vv[u].x, acc.x);
-            acc.y = fmaf(pr, vv[u].y, acc.y);
-            acc.z = fmaf(pr, vv[u].z, acc.z);
-            acc.w = fmaf(pr, vv[u].w, acc.w);
+            float vf[DPL];
+            widen(vv[u], vf);
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) acc[i] = fmaf(pr, vf[i], acc[i]);
         }
         m = mx;
     }
-    *reinterpret_cast<float4*>(&sm_o[sid][4 * c]) = acc;
+#pragma unroll
+    for (int i = 0; i < DPL; i += 4) *reinterpret_cast<float4*>(&sm_o[sid][DPL * c + i]) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
     if (c == 0) {
         sm_m[sid] = m;
         sm_l[sid] = l;
@@ -667,11 +760,11 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     if (wave != 0) return;  // wave-uniform: only wave 0 publishes / merges
     float M = sm_m[0];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) M = fmaxf(M, sm_m[i]);
+    for (int i = 1; i < NSTR; ++i) M = fmaxf(M, sm_m[i]);
     float o = 0.f, L = 0.f;
     if (M > -INFINITY) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NSTR; ++i) {
             const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
             o = fmaf(w, sm_o[i][lane], o);
             L = fmaf(w, sm_l[i], L);
@@ -734,8 +827,13 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     const bool nt = variant == 2 ? p.nt != 0 : variant != 0;
     // non-temporal K/V loads: 18.6 vs 20.4 us per medium.en cross-attention launch; default policy only when a whole decode
     // step fits the Infinity Cache (engine.hip: wt_decoder_begin)
-    if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((dec_attn_kernel<4, false>), grid, dim3(256), 0, s, p);
+    if (p.kv_half) {
+        if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dec_attn_kernel<4, false, true>), grid, dim3(256), 0, s, p);
+    } else {
+        if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dec_attn_kernel<4, false, false>), grid, dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 
@@ -899,7 +997,7 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
     const float4* pe = reinterpret_cast<const float4*>(p.pos_emb + (size_t)s_pos * p.d_model);
     for (int i = tid; i < p.B * d4; i += 256) {
         const int b = i / d4, c = i - b * d4;
-        const float4 a = reinterpret_cast<const float4*>(p.tok_emb + (size_t)s_tok[b] * p.d_model)[c], q = pe[c];
+        const float4 a = load_emb4(p.tok_emb, (size_t)s_tok[b] * p.d_model + 4 * c, p.emb_half != 0), q = pe[c];
         reinterpret_cast<float4*>(p.next_x + (size_t)b * p.d_model)[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
     }
 }

@@ -236,6 +236,14 @@ __global__ __launch_bounds__(256, HBK_ == 64 ? 2 : 3) void gemm_f16_kernel(const
                 float v = acc[ti][tj][r] + bv;
                 if (p.act) v = gelu_erf_h(v);
                 const int cb = m / p.c_rows_per_batch, cr = m - cb * p.c_rows_per_batch;
+                if (p.epi == EPI_KV_HEADS) {   // cross-K/V projection of an fp16 decoder engine: head-split caches [b][h][kv_cap][64]
+                    const int dm = p.kv_heads * HEAD_DIM, which = n / dm, nn = n - which * dm;
+                    float* base = which ? p.C2 : p.C;
+                    const long long at = (((long long)cb * p.kv_heads + (nn >> 6)) * p.kv_cap + p.kv_seq_off + cr) * HEAD_DIM + (nn & 63);
+                    if (OUT_HALF) reinterpret_cast<__half*>(base)[at] = __float2half(v);
+                    else base[at] = v;
+                    continue;
+                }
                 if (p.pos) v += p.pos[(long long)cr * p.N + n];
                 const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
                 if (p.resid) v += p.resid[off];
@@ -288,6 +296,20 @@ __device__ __forceinline__ void hgemm_epilogue_lds(const GemmParams& p, const f3
             if (mw + o >= p.M) continue;
             int cb = cb_w, cr = cr_w + o;
             while (cr >= p.c_rows_per_batch) { cr -= p.c_rows_per_batch; ++cb; }
+            if (p.epi == EPI_KV_HEADS) {   // head-split K/V caches [b][h][kv_cap][64]: a lane's four columns never leave their head
+                if (n >= p.N) continue;    // N = 2 * heads * 64: a multiple of 4, so n < N covers n + 3
+                const int dm = p.kv_heads * HEAD_DIM, which = n / dm, nn = n - which * dm;
+                float* base = which ? p.C2 : p.C;
+                const long long at = (((long long)cb * p.kv_heads + (nn >> 6)) * p.kv_cap + p.kv_seq_off + cr) * HEAD_DIM + (nn & 63);
+                if (OUT_HALF) {
+                    __half2* dst = reinterpret_cast<__half2*>(reinterpret_cast<__half*>(base) + at);
+                    dst[0] = __floats2half2_rn(a.x + bv.x, a.y + bv.y);
+                    dst[1] = __floats2half2_rn(a.z + bv.z, a.w + bv.w);
+                } else {
+                    *reinterpret_cast<float4*>(base + at) = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+                }
+                continue;
+            }
             const long long off = (long long)cb * p.c_batch_stride + (long long)cr * p.ldc + n;
             float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
             if (p.act) {
@@ -763,7 +785,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
 
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
-    if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7) || p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
+    if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7)) return hipErrorInvalidValue;
+    const bool kv = p.epi == EPI_KV_HEADS;   // cross-K/V projection of an fp16 decoder engine: 128x128 kernels only (generic epilogues)
+    if (kv && (p.N != 2 * p.kv_heads * HEAD_DIM || !p.C2 || p.resid || p.pos || p.act || (reinterpret_cast<uintptr_t>(p.C) & 15) ||
+               (reinterpret_cast<uintptr_t>(p.C2) & 15) || (reinterpret_cast<uintptr_t>(p.bias) & 15)))
+        return hipErrorInvalidValue;
+    if (!kv && p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
     static PerDeviceFlag attr_set;
     static int bk = 32;
     if (!attr_set.get()) {
@@ -787,7 +814,7 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
     static const int env_variant = tuning_env("WT_HGEMM_VARIANT") ? atoi(tuning_env("WT_HGEMM_VARIANT")) : 0;
     const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach both kernels at small sizes
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
-    const bool use3 = variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 ? false : p.M >= 16384;
+    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 ? false : p.M >= 16384;
     if (dma_ok && use3) {
         static PerDeviceFlag attr3;
         if (!attr3.get()) {

@@ -68,6 +68,8 @@ struct SkinnyParams {
     int d_model, s_cap;    // QKV_APPEND
     float q_scale;         // QKV_APPEND: multiply the q third by this (head_dim^-0.5)
     int parts_nsplit, parts_H;
+    int w_half;            // W (and only W) is IEEE half [N][K]: fp16 decoder engines; K-slices must be multiples of 8
+    int kv_half;           // QKV_APPEND: the self caches are IEEE half (resident caches of an fp16 engine's fast path)
     // YMODE_ARGMAX (vocabulary projection of the greedy fast path): the logits never reach HBM unless a trace is requested.
     // Every workgroup reduces its rows to one masked (max, argmax) per batch row: am_val / am_idx [B][am_ld], column = workgroup.
     const uint8_t* am_mask;  // [N] bit0: always suppressed, bit1: suppressed when cur_len == am_begin_index
@@ -96,6 +98,7 @@ struct DecAttnParams {
     const float* ln_h;     // [B][d] residual stream whose LayerNorm statistics normalise q
     const float* ln_r;     // [d] row sums of s.Wq.diag(gamma)
     const float* ln_t;     // [d] s.(Wq.beta + bq)
+    int kv_half;           // kcache / vcache are IEEE half (fp16 decoder engines keep their RESIDENT caches in fp16; fp32 arithmetic)
 };
 
 // A/B tuning switches (WT_NSPLIT_CROSS, WT_GEMM_NO_DMA, ...; DESIGN.md "Tuning knobs") are lab tools, not part of the C-ABI's
@@ -149,7 +152,7 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
 hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S, int H, hipStream_t s);  // half in, half out  // p.A / p.W point at __half data
 
 hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
-                            int d, const DecState* st, hipStream_t s);
+                            int d, const DecState* st, hipStream_t s, int emb_half = 0);   // emb_half: tok_emb is IEEE half
 hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s);
 int skinny_grid(const SkinnyParams& p);  // workgroups launch_skinny uses for p (column count of am_val / am_idx), -1 if p is invalid
 // two independent skinny GEMMs (same batch) in ONE launch: blocks [0, grid_a) run `a`, the rest run `b`
@@ -172,6 +175,7 @@ struct SelectParams {
     float* next_x;         // [B][d] decoder input of the next step, or nullptr
     int d_model;
     int B, V, max_length, begin_index, eos, pad, force_eos_step;
+    int emb_half;          // tok_emb is IEEE half (fp16 decoder engines)
 };
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, hipStream_t s);
