@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch16", action="store_true", help="skip the secondary batch-16 measurement")
+    ap.add_argument("--no-varlen", action="store_true", help="skip the variable-length (LibriSpeech-like) workload")
+    ap.add_argument("--no-fp16-decoder", action="store_true", help="skip the fp16-engine (encoder + decoder) batch-16 measurement")
+    ap.add_argument("--varlen-utterances", type=int, default=64, help="utterances per GPU in the variable-length workload")
     ap.add_argument("--cpu-decode-steps", type=int, default=128, help="decoder steps timed on the CPU (about 10 s of CPU work in total)")
     ap.add_argument("--encoder-precision", default="float32", choices=["float32", "float16"],
                     help="float16 = BASELINE config 4 (fp16 encoder + fp32 decoder); the headline metric is float32")
@@ -140,6 +143,73 @@ def main():
         barrier()
         value_b16 = 30.0 * 16 * world / el16
 
+    # secondary figure: the realistic-transcript regime.  A seeded LibriSpeech-like set of utterances per GPU (durations and
+    # transcript lengths modelled on test-clean, synthetic.librispeech_like_lengths; each log-mel is padded behind its audio like a
+    # real clip, row i is made to emit EOS at its own step), decoded in batches of B: once in dataset order (what cal_wer.py did
+    # until round 3) and once with length-aware batching (sharding.length_sorted_batches over the duration recovered from the mel's
+    # trailing padding).  Slot utilisation = sum of row lengths / sum over batches of B x longest row.
+    varlen = None
+    if not args.no_varlen:
+        n_utt = args.varlen_utterances
+        dur, eos_steps = w.synthetic.librispeech_like_lengths(n_utt, seed=rank, max_length=args.max_length)
+        vmel = torch.from_numpy(np.stack([w.synthetic.make_mel_padded(cfg, rank * n_utt + i, dur[i]) for i in range(n_utt)])).cuda()
+
+        def run_groups(groups):
+            for g in groups:
+                dec.generate(enc(vmel[g]), force_eos_steps=[eos_steps[i] for i in g])
+
+        def time_groups(groups):
+            run_groups(groups[:1])
+            barrier()
+            t = time.perf_counter()
+            run_groups(groups)
+            torch.cuda.synchronize()
+            el = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+            barrier()
+            return el
+
+        in_order = [list(range(a, b)) for a, b in w.sharding.batches(0, n_utt, B)]
+        by_length = w.sharding.length_sorted_batches(w.audio.valid_frames(vmel), B)
+        row_steps = [s_ + 1 for s_ in eos_steps]
+        el_order, el_sorted = time_groups(in_order), time_groups(by_length)
+        varlen = {"utterances_per_gpu": n_utt, "mean_duration_s": round(float(np.mean(dur)), 2), "mean_decoder_steps": round(float(np.mean(row_steps)), 1),
+                  "max_decoder_steps": int(max(row_steps)),
+                  "dataset_order": {"value": round(30.0 * n_utt * world / el_order, 2), "real_audio_s_per_s": round(float(np.sum(dur)) * world / el_order, 2),
+                                    "slot_utilisation": round(w.sharding.slot_utilisation(row_steps, in_order), 4)},
+                  "length_sorted": {"value": round(30.0 * n_utt * world / el_sorted, 2), "real_audio_s_per_s": round(float(np.sum(dur)) * world / el_sorted, 2),
+                                    "slot_utilisation": round(w.sharding.slot_utilisation(row_steps, by_length), 4)},
+                  "note": "value = 30 s windows per second as in the headline; lengths modelled on LibriSpeech test-clean (no dataset on the box), "
+                          "EOS forced per row; rank r uses seed r"}
+        del vmel
+
+    # secondary figure: fp16 ENGINES (build_encoder.py / build_decoder.py --engine_precision float16): half GEMM / GEMV operands and
+    # half resident K/V caches, fp32 accumulate / softmax / LayerNorm / residual; batch 16.  Never the headline (which is fp32).
+    fp16 = None
+    if B == 8 and not args.no_fp16_decoder and not args.no_batch16:
+        enc_h = w.WhisperEncoderEngine(w.convert.build_encoder_engine(cfg, weights, precision="float16"))
+        dec_h = w.WhisperDecoderEngine(w.convert.build_decoder_engine(cfg, weights, precision="float16"), cfg)
+        pass_h = lambda: dec_h.generate(enc_h(mel16))
+        pass_h()
+        barrier()
+        th = time.perf_counter()
+        pass_h()
+        torch.cuda.synchronize()
+        elh = w.sharding.max_over_ranks(time.perf_counter() - th, dist)
+        barrier()
+        fp16 = {"value": round(30.0 * 16 * world / elh, 2), "ms_per_pass": round(elh * 1e3, 2)}
+        if rank == 0 and not args.no_roofline:
+            dec_h.begin(enc_h(mel16))
+            dec_h.steps(args.max_length - 1)
+            dec_h.poll()
+            Fd_ = cfg["decoder_ffn_dim"]
+            kinds_h = {"qkv": 3 * d * d * 2, "self_attn": 16 * H * (args.max_length - 1) * 64 * 2 * 2, "pair": 3 * d * d * 2, "cross_attn": 16 * H * S * 64 * 2 * 2,
+                       "cross_out": d * d * 2, "fc1": d * Fd_ * 2, "fc2": d * Fd_ * 2}
+            fp16["roofline_skinny"] = {}
+            for kind, nbytes in kinds_h.items():
+                us = dec_h.time_kernel(kind, iters=20)
+                fp16["roofline_skinny"][kind] = {"bytes_per_launch": int(nbytes), "avg_launch_us": round(us, 2), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+        del enc_h, dec_h
+
     out = {
         "metric": f"audio-sec/s, {args.model} fp32 greedy", "value": round(value, 2), "unit": "audio-seconds/second",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -148,8 +218,14 @@ def main():
                                f"encoder + {args.max_length - 1} decoder steps (max_length {args.max_length}), random-init weights",
                    "batch_per_gpu": B, "decode_steps": args.max_length - 1, "sharding": f"utterance-parallel x{world}, no collective",
                    "value_n32_decode_steps": round(value_n32, 2),
-                   "value_batch16_per_gpu": round(value_b16, 2) if value_b16 else None, "wer": None},
+                   "value_batch16_per_gpu": round(value_b16, 2) if value_b16 else None,
+                   "value_varlen": varlen["length_sorted"]["value"] if varlen else None,
+                   "value_fp16_decoder_b16": fp16["value"] if fp16 else None, "wer": None},
     }
+    if varlen:
+        out["varlen"] = varlen
+    if fp16:
+        out["fp16_engines_b16"] = fp16
 
     if rank == 0 and not args.no_roofline:
         # per-kernel durations: an instrumented eager pass with hipEvents around every launch of the timed kernels
@@ -189,7 +265,7 @@ def main():
         attn_flop = B * cfg["encoder_layers"] * 4 * H * S * S * 64
         half = args.encoder_precision == "float16"
         enc_peak = 2500.0 if half else MFMA_F32_PEAK_TF
-        out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+        out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
                                    "achieved": round(gemm_tf, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(gemm_tf / enc_peak, 4),
                                    "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
                                    "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,

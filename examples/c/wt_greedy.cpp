@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     gp.suppress_tokens = suppress.data(); gp.n_suppress_tokens = (int)suppress.size();
     gp.begin_suppress_tokens = begin_suppress.data(); gp.n_begin_suppress_tokens = (int)begin_suppress.size();
     gp.forced_decoder_ids = forced.data(); gp.n_forced = (int)forced.size() / 2;
-    gp.force_eos_step = -1; gp.logits_trace = nullptr;
+    gp.force_eos_step = -1; gp.logits_trace = nullptr; gp.force_eos_steps = nullptr;
 
     wt_engine *enc = nullptr, *dec = nullptr;
     WT(wt_engine_open(enc_blob.data(), enc_blob.size(), 0, &enc));

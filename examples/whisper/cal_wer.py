@@ -29,6 +29,10 @@ def parse_arguments():
     parser.add_argument("--engine_dir", type=str, default="whisper_outputs")
     parser.add_argument("--cache", type=str, default="librispeech.cache")
     parser.add_argument("--batch", type=int, default=8)
+    parser.add_argument("--batching", choices=["sorted", "dataset"], default="sorted",
+                        help="sorted (default): length-aware batches -- utterances ordered by the audio duration recovered from the "
+                             "log-mel's trailing padding, so a batch does not decode on behind one long row; dataset: contiguous order")
+    parser.add_argument("--dist-backend", type=str, default=None, help="nccl (= RCCL) | gloo; default: nccl when every rank has its own GPU")
     parser.add_argument("--log_level", type=str, default="error")
     return parser.parse_args()
 
@@ -44,7 +48,7 @@ def get_normalizer(whisper_dir):
 if __name__ == "__main__":
     args = parse_arguments()
     tensorrt_llm.logger.set_level(args.log_level)
-    rank, world, device, dist = tensorrt_llm.sharding.init_from_env()
+    rank, world, device, dist = tensorrt_llm.sharding.init_from_env(args.dist_backend)
     torch.cuda.set_device(device)
     with open(os.path.join(args.engine_dir, "config.pkl"), "rb") as f:
         config = pickle.load(f)
@@ -53,16 +57,20 @@ if __name__ == "__main__":
     tok = WhisperTokenDecoder.from_dir(args.whisper)
     with open(args.cache, "rb") as f:
         dataset = pickle.load(f)
-    begin, end = tensorrt_llm.sharding.utterance_shard(len(dataset), world, rank)   # this rank's contiguous shard
-    hypotheses, references = [], []
-    for b0, b1 in tensorrt_llm.sharding.batches(begin, end, args.batch):
-        chunk = dataset[b0:b1]
-        mel = torch.stack([torch.as_tensor(m, dtype=torch.float32) for m, _ in chunk]).cuda()
+    if args.batching == "sorted":   # every rank gets the same mix of long and short batches (round-robin over the sorted batches)
+        lengths = [tensorrt_llm.audio.valid_frames(torch.as_tensor(m, dtype=torch.float32))[0] for m, _ in dataset]
+        groups = tensorrt_llm.sharding.length_sorted_batches(lengths, args.batch, world, rank)
+    else:
+        begin, end = tensorrt_llm.sharding.utterance_shard(len(dataset), world, rank)   # this rank's contiguous shard
+        groups = [list(range(b0, b1)) for b0, b1 in tensorrt_llm.sharding.batches(begin, end, args.batch)]
+    indexed = []
+    for g in groups:
+        mel = torch.stack([torch.as_tensor(dataset[i][0], dtype=torch.float32) for i in g]).cuda()
         ids = dec.generate(enc(mel)).cpu().tolist()
-        hypotheses += tok.batch_decode(ids, skip_special_tokens=True)
-        references += [t for _, t in chunk]
-    hypotheses = tensorrt_llm.sharding.gather_objects(hypotheses, dist)             # rank order == utterance order
-    references = tensorrt_llm.sharding.gather_objects(references, dist)
+        indexed += list(zip(g, tok.batch_decode(ids, skip_special_tokens=True)))
+    indexed = sorted(tensorrt_llm.sharding.gather_objects(indexed, dist))            # back to dataset order on the host
+    hypotheses = [h for _, h in indexed]
+    references = [t for _, t in dataset]
     if rank == 0:
         assert len(hypotheses) == len(dataset)
         normalizer = get_normalizer(args.whisper)

@@ -42,6 +42,9 @@ def parse_arguments():
                         "front-end, i.e. what hf_processor does in the reference, run.py:267); with --whisper <checkpoint dir> the ids "
                         "are also decoded to text (vocab.json)")
     parser.add_argument("--max_length", type=int, default=None)
+    parser.add_argument("--batching", choices=["sorted", "dataset"], default="sorted",
+                        help="fast path: length-aware batches (by the audio duration recovered from the log-mel's trailing padding) or dataset order")
+    parser.add_argument("--dist-backend", type=str, default=None, help="nccl (= RCCL) | gloo; default: nccl when every rank has its own GPU")
     parser.add_argument("--dump_ids", type=str, default=None, help="rank 0 writes the fast-path token ids as JSON (tests)")
     return parser.parse_args()
 
@@ -127,7 +130,7 @@ def decode_with_sessions(whisperencoder, whisperdecoder, config, mel):
 if __name__ == "__main__":
     args = parse_arguments()
     tensorrt_llm.logger.set_level(args.log_level)
-    rank, world, device, dist = tensorrt_llm.sharding.init_from_env()
+    rank, world, device, dist = tensorrt_llm.sharding.init_from_env(args.dist_backend)
     torch.cuda.set_device(device)
     if world > 1 and (args.session or args.compare):
         raise SystemExit("the Session path is the reference's batch-1 single-GPU protocol: run --session / --compare without torchrun")
@@ -151,18 +154,24 @@ if __name__ == "__main__":
     if not args.session:
         enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
         dec = tensorrt_llm.WhisperDecoderEngine(open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config)
-        begin, end = tensorrt_llm.sharding.utterance_shard(len(mels), world, rank)   # this rank's contiguous shard
+        if args.batching == "sorted":
+            lengths = [tensorrt_llm.audio.valid_frames(m)[0] for m in mels]
+            groups = tensorrt_llm.sharding.length_sorted_batches(lengths, 8, world, rank)
+        else:
+            begin, end = tensorrt_llm.sharding.utterance_shard(len(mels), world, rank)   # this rank's contiguous shard
+            groups = [list(range(b0, b1)) for b0, b1 in tensorrt_llm.sharding.batches(begin, end, 8)]
         for _ in range(2):  # the first pass is the warm-up, as in run.py:260
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.time()
-            ids = []
-            for b0, b1 in tensorrt_llm.sharding.batches(begin, end, 8):
-                ids += dec.generate(enc(torch.cat(mels[b0:b1]))).cpu().tolist()
+            indexed = []
+            for g in groups:
+                indexed += list(zip(g, dec.generate(enc(torch.cat([mels[i] for i in g]))).cpu().tolist()))
             torch.cuda.synchronize()
             elapsed = tensorrt_llm.sharding.max_over_ranks(time.time() - t0, dist)
-            results["fast"] = (elapsed, tensorrt_llm.sharding.gather_ids(ids, dist))
+            ids = [row for _, row in sorted(tensorrt_llm.sharding.gather_objects(indexed, dist))]   # dataset order, on the host
+            results["fast"] = (elapsed, ids)
         if rank == 0:
             print(f"fast path   : {results['fast'][0]:.3f} s for {len(mels)} x 30 s on {world} rank(s)  ({30 * len(mels) / results['fast'][0]:.1f} audio-s/s)")
             if args.dump_ids:

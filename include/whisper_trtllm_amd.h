@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 1
+#define WT_ABI_VERSION 2
 
 /* error codes */
 #define WT_OK 0
@@ -116,6 +116,8 @@ typedef struct {
     int32_t n_forced;
     int32_t force_eos_step;           /* bench only: emit EOS at this 0-based step for every row; -1 = off */
     float* logits_trace;              /* optional device buffer f32 [batch, max_length-1, V] of raw logits, or NULL */
+    const int32_t* force_eos_steps;   /* bench only: host array [batch], row b emits EOS at 0-based step force_eos_steps[b]
+                                         (< 0: never) -- the variable-length workload of bench.py; NULL = off */
 } wt_greedy_params;
 
 /* (6) start a greedy decode of `batch` utterances (1 <= batch <= 16 per call, WT_E_UNSUPPORTED above; shard larger
@@ -134,10 +136,17 @@ int wt_decoder_steps(wt_engine* dec, int n_steps, void* stream);
 /* (8) synchronise `stream` and report progress: current sequence length (prompt included), number of
  * unfinished rows, and whether the stop test of run.py:219-226 has fired. */
 int wt_decoder_poll(wt_engine* dec, int* cur_len, int* n_unfinished, int* done, void* stream);
+/* (8b) run the decode in flight to its stop test (run.py:195-226): enqueues steps one at a time, keeping `lookahead` steps queued
+ * behind the one the GPU is executing (0 = engine default: 1 for the large models, 3 when a step is < ~0.3 ms), and follows the
+ * progress through a pinned host word the last kernel of every step writes -- no stream synchronisation, no idle GPU between
+ * chunks, and at most `lookahead` steps enqueued past the stop (they are no-ops for the token state).  Returns once the stop test
+ * has been OBSERVED; the surplus steps may still be draining, so follow it with stream-ordered calls (wt_decoder_read_ids).
+ * `*cur_len` = final sequence length (prompt included), `*n_unfinished` = rows that never produced EOS. */
+int wt_decoder_run(wt_engine* dec, int lookahead, int* cur_len, int* n_unfinished, void* stream);
 /* copy the generated ids (int32 [batch, cur_len], row-major) into a DEVICE buffer of capacity
  * batch*max_length int32; stream-ordered. */
 int wt_decoder_read_ids(wt_engine* dec, int32_t* ids_out, int ld, void* stream);
-/* (9) convenience: begin + steps/poll until done; writes ids int32 [batch, max_length] (row stride
+/* (9) convenience: begin + wt_decoder_run; writes ids int32 [batch, max_length] (row stride
  * max_length) to DEVICE memory and the final length to *out_len.  Synchronises the stream. */
 int wt_decoder_greedy(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p,
                       int32_t* ids_out, int* out_len, void* stream);

@@ -256,7 +256,8 @@ def greedy_search(W: Weights, cfg: dict, enc_out: torch.Tensor, max_length: Opti
 
     Starts from [[decoder_start_token_id]] per row (run.py:273); stops when every row has emitted EOS or
     len >= max_length (MaxLengthCriteria, HF stopping_criteria.py:61-70).  `force_eos_at=n` (bench only)
-    makes step n emit EOS for every row, emulating a LibriSpeech-length transcript on random weights."""
+    makes step n emit EOS for every row, emulating a LibriSpeech-length transcript on random weights; a sequence of B
+    entries does so per row (entry < 0: never) -- the variable-length workload of bench.py."""
     B = enc_out.shape[0]
     max_length = cfg["max_length"] if max_length is None else max_length
     eos, pad = cfg["eos_token_id"], cfg["pad_token_id"]
@@ -272,8 +273,13 @@ def greedy_search(W: Weights, cfg: dict, enc_out: torch.Tensor, max_length: Opti
             all_logits.append(nxt_logits.clone())
         scores = apply_logits_processors(cfg, ids.shape[1], 1, nxt_logits)
         nxt = torch.argmax(scores, dim=-1)
-        if force_eos_at is not None and step == force_eos_at:
-            nxt = torch.full_like(nxt, eos)
+        if force_eos_at is not None:
+            if isinstance(force_eos_at, int):
+                if step == force_eos_at:
+                    nxt = torch.full_like(nxt, eos)
+            else:
+                hit = torch.tensor([int(f) == step for f in force_eos_at], dtype=torch.bool)
+                nxt = torch.where(hit, torch.full_like(nxt, eos), nxt)
         nxt = nxt * unfinished + pad * (1 - unfinished)                            # utils.py:1509
         ids = torch.cat([ids, nxt[:, None]], dim=-1)
         unfinished = unfinished * (nxt != eos).long()                              # utils.py:1514

@@ -134,6 +134,51 @@ def test_stepwise_api_and_noop_steps_after_stop(wt):
         wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg).steps(1)   # steps before begin
 
 
+@pytest.mark.parametrize("case", ["toy-short_b3", "toy-short-eos1_b3", "toy-short-eosall_b3", "tiny_b2"])
+def test_run_loop_and_chunked_poll_agree_with_golden(wt, case):
+    """wt_decoder_run (host mailbox, `lookahead` steps queued) against the begin/steps/poll protocol and the golden ids, for every
+    lookahead; decodes follow each other without a synchronisation, so surplus no-op steps of one decode are still draining when
+    the next one begins (their mailbox words carry the old epoch and must be ignored)."""
+    z, cfg, weights, mel = load_case(case)
+    enc, dec = _engines(wt, cfg, weights)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    outs = [dec.generate(hidden, lookahead=la) for la in (0, 1, 2, 5, 64)] + [dec.generate(hidden, chunk=8), dec.generate(hidden, chunk=3)]
+    for ids in outs:
+        np.testing.assert_array_equal(ids.cpu().numpy(), z["ids"])
+    dec.begin(hidden)
+    cur, nu = dec.run()
+    assert cur == z["ids"].shape[1]
+    cur2, nu2, done = dec.poll()      # the device state agrees with what the mailbox reported
+    assert (cur2, nu2, done) == (cur, nu, True)
+    dec.steps(4)                      # steps after the stop stay no-ops, also for the mailbox protocol
+    assert dec.run() == (cur, nu)
+    np.testing.assert_array_equal(dec.read_ids(cur).cpu().numpy(), z["ids"])
+
+
+@pytest.mark.parametrize("B", [3, 8, 16])
+def test_per_row_forced_eos_matches_oracle(wt, B):
+    """The variable-length workload of bench.py: row b is made to emit EOS at its own step (cpu_ref force_eos_at=[...]); finished
+    rows pad, the batch stops when its longest row does, ids equal the oracle's."""
+    import cpu_ref
+    cfg = wt.synthetic.get_config("toy-short")
+    cfg["max_length"] = 24
+    weights = wt.synthetic.make_weights(cfg, 11)
+    mel = wt.synthetic.make_mel(cfg, index=70, batch=B)
+    rows = [int(x) for x in np.random.default_rng(B).integers(0, 20, B)]
+    rows[1] = -1 if B == 3 else rows[1]          # one row that is never forced (runs to max_length unless it emits EOS itself)
+    enc, dec = _engines(wt, cfg, weights)
+    hidden = enc(torch.from_numpy(mel).cuda())
+    ids = dec.generate(hidden, force_eos_steps=rows).cpu().numpy()
+    W = cpu_ref.to_torch(weights)
+    with torch.no_grad():
+        ref = cpu_ref.greedy_search(W, cfg, cpu_ref.encoder_forward(W, cfg, torch.from_numpy(mel)), force_eos_at=rows).numpy()
+        ref_free = cpu_ref.greedy_search(W, cfg, cpu_ref.encoder_forward(W, cfg, torch.from_numpy(mel))).numpy()
+    np.testing.assert_array_equal(ids, ref)
+    np.testing.assert_array_equal(dec.generate(hidden).cpu().numpy(), ref_free)   # the per-row table is off again
+    with pytest.raises(ValueError):
+        dec.generate(hidden, force_eos_steps=rows[:-1])
+
+
 @pytest.mark.parametrize("cname,seed", [("toy-short", 41), ("toy-wide", 42)])
 def test_full_batch_of_eight_matches_oracle(wt, cname, seed):
     """B = 8 (the batch the metric is quoted on; NB=8 kernel instantiations) end to end against the CPU oracle."""

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert names, header
         for n in sorted(names):
             assert hasattr(lib, n), f"{n} declared in {header} but not exported"
-    assert lib.wt_abi_version() == 1
+    assert lib.wt_abi_version() == 2
 
 
 def test_open_rejects_garbage_and_reports():

@@ -12,11 +12,11 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_float, c_int, c_int32
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libwhisper_trtllm_amd.so")
 WT_NAME_LEN, WT_MAX_DIMS = 48, 6
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "wt_engine_open", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
-    "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_read_ids",
+    "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_run", "wt_decoder_read_ids",
     "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
@@ -44,7 +44,7 @@ class GreedyParams(Structure):
                 ("suppress_tokens", POINTER(c_int32)), ("n_suppress_tokens", c_int32),
                 ("begin_suppress_tokens", POINTER(c_int32)), ("n_begin_suppress_tokens", c_int32),
                 ("forced_decoder_ids", POINTER(c_int32)), ("n_forced", c_int32),
-                ("force_eos_step", c_int32), ("logits_trace", c_void_p)]
+                ("force_eos_step", c_int32), ("logits_trace", c_void_p), ("force_eos_steps", POINTER(c_int32))]
 
 
 class KernelTimer(Structure):
@@ -87,6 +87,7 @@ def load():
     lib.wt_decoder_begin.argtypes = [c_void_p, c_void_p, c_int, POINTER(GreedyParams), c_void_p]
     lib.wt_decoder_steps.argtypes = [c_void_p, c_int, c_void_p]
     lib.wt_decoder_poll.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p]
+    lib.wt_decoder_run.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_void_p]
     lib.wt_decoder_read_ids.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
     lib.wt_decoder_greedy.argtypes = [c_void_p, c_void_p, c_int, POINTER(GreedyParams), c_void_p, POINTER(c_int), c_void_p]
     lib.wt_engine_set_profiling.argtypes = [c_void_p, c_int]

@@ -59,6 +59,20 @@ def dft_tables(n_fft: int = N_FFT):
     return m.astype(np.float32), ndft
 
 
+def valid_frames(mel) -> list:
+    """Frames of real audio in each log-mel of a batch `[B, n_mels, T]` (torch tensor, any device): T minus the trailing run of
+    frames identical to the last one.  A clip shorter than the 30 s window is zero-padded as a waveform
+    (feature_extraction_whisper.py:229-250), so its padding frames are identical columns; a full window has no such run.
+    Used as the length proxy of `sharding.length_sorted_batches`."""
+    import torch
+    if mel.dim() == 2:
+        mel = mel[None]
+    is_pad = (mel == mel[:, :, -1:]).all(dim=1)                  # [B, T]
+    run = is_pad.flip(1).to(torch.int32).cumprod(dim=1).sum(dim=1)
+    run = torch.where(run <= 1, torch.zeros_like(run), run)     # the last frame alone is not a padding run
+    return [int(v) for v in (mel.shape[2] - run).cpu()]
+
+
 class LogMelFrontend:
     """waveforms float32 [B, n] on the GPU (16 kHz mono) -> log-mel float32 [B, 80, 3000]; asynchronous."""
 

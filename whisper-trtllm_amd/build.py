@@ -38,15 +38,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        cmds.append([_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
+                     "-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    # translation units are independent: compile them side by side (the three kernel files take ~25 s each)
+    procs = []
+    for cmd in cmds:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+        procs.append(subprocess.Popen(cmd))
+    failed = [cmd for cmd, pr in zip(cmds, procs) if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

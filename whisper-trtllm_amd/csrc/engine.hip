@@ -94,6 +94,13 @@ struct wt_engine {
     std::vector<int> h_forced;
     bool tables_valid = false;
     DecState* h_state = nullptr;  // pinned
+    unsigned long long* mailbox = nullptr;      // pinned, coherent host word greedy_finish_kernel reports every step into (wt_decoder_run)
+    unsigned long long* mailbox_dev = nullptr;  // its device address
+    int epoch = 0;                // wt_decoder_begin count (tags the mailbox word: late no-op steps of the previous decode are ignored)
+    int issued = 0;               // decoder steps enqueued since wt_decoder_begin
+    int* force_rows = nullptr;    // device [16]: per-row forced-EOS steps (bench-only variable-length workload)
+    std::vector<int> h_force_rows;
+    bool force_rows_on = false;
     // greedy session
     bool begun = false;
     int B = 0, max_length = 0, begin_index = 0, eos = 0, pad = 0, force_eos_step = -1, nsplit_self = 1, nsplit_cross = 4;
@@ -164,6 +171,7 @@ extern "C" void wt_engine_close(wt_engine* e) {
     }
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     if (e->h_state) hipHostFree(e->h_state);
+    if (e->mailbox) hipHostFree((void*)e->mailbox);
     if (e->enc_ws) hipFree(e->enc_ws);
     if (e->dec_ws) hipFree(e->dec_ws);
     if (e->weights_base) hipFree(e->weights_base);
@@ -455,17 +463,23 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     const size_t o_selv = take((size_t)B * SEL_PARTS_CAP * 4), o_seli = take((size_t)B * SEL_PARTS_CAP * 4);
     const size_t o_part = take((size_t)B * e->H * 16 * PART_STRIDE * 4), o_lg = take((size_t)B * e->V * 4);
     const size_t o_st = take(sizeof(DecState)), o_ids = take((size_t)B * cap_len * 4), o_unf = take((size_t)B * 4);
-    const size_t o_forced = take((size_t)(cap_len + 1) * 4), o_mask = take((size_t)e->V);
+    const size_t o_forced = take((size_t)(cap_len + 1) * 4), o_mask = take((size_t)e->V), o_frows = take(16 * 4);
     hipError_t he = hipMalloc((void**)&e->dec_ws, off);
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for decoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     char* b = e->dec_ws;
     e->self_k = (float*)(b + o_sk); e->self_v = (float*)(b + o_sv); e->cross_k = (float*)(b + o_ck); e->cross_v = (float*)(b + o_cv);
     e->dh = (float*)(b + o_h); e->dh2 = (float*)(b + o_h2); e->dq = (float*)(b + o_q); e->datt = (float*)(b + o_att); e->att_cnt = (int*)(b + o_cnt); e->sel_val = (float*)(b + o_selv); e->sel_idx = (int*)(b + o_seli); e->dffn = (float*)(b + o_f); e->part = (float*)(b + o_part);
     e->logits = (float*)(b + o_lg); e->st = (DecState*)(b + o_st); e->ids = (int*)(b + o_ids); e->unfinished = (int*)(b + o_unf);
-    e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask);
+    e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask); e->force_rows = (int*)(b + o_frows);
+    e->h_force_rows.clear();
     e->enc_h = e->w_half ? (void*)(b + o_ench) : nullptr;
     HIPCHK(hipMemset(e->att_cnt, 0, (size_t)B * e->H * 4));  // arrival tickets start (and are left) at zero
     if (!e->h_state) HIPCHK(hipHostMalloc((void**)&e->h_state, sizeof(DecState), hipHostMallocDefault));
+    if (!e->mailbox) {
+        HIPCHK(hipHostMalloc((void**)&e->mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *e->mailbox = 0;
+        HIPCHK(hipHostGetDevicePointer((void**)&e->mailbox_dev, (void*)e->mailbox, 0));
+    }
     if (!e->own_stream) {
         HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     }
@@ -682,6 +696,18 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         HIPCHK(hipStreamSynchronize(s));  // pageable sources: make sure the copies have left the host images before they can change
         e->tables_valid = true;
     }
+    {   // bench-only per-row transcript lengths: uploaded (with one synchronisation) only when they change
+        std::vector<int> rows;
+        if (p->force_eos_steps) rows.assign(p->force_eos_steps, p->force_eos_steps + B);
+        const bool on = !rows.empty();
+        if (on && rows != e->h_force_rows) {
+            e->h_force_rows.swap(rows);
+            HIPCHK(hipMemcpyAsync(e->force_rows, e->h_force_rows.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        if (on != e->force_rows_on) e->graph_valid = false;
+        e->force_rows_on = on;
+    }
     const bool same = e->begun && e->B == B && e->max_length == p->max_length && e->trace == p->logits_trace &&
                       e->begin_index == p->begin_index && e->eos == p->eos_token_id && e->pad == p->pad_token_id &&
                       e->force_eos_step == p->force_eos_step;
@@ -711,7 +737,9 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         e->nsplit_self = ns;
     }
     e->nsplit_cross = tuning_env("WT_NSPLIT_CROSS") ? atoi(tuning_env("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
-    LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, s));
+    e->epoch = e->epoch % 0xffff + 1;   // 1..65535: never the value of a freshly zeroed mailbox
+    e->issued = 0;
+    LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, e->epoch, s));
     LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s, e->w_half));  // input of step 0
     rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, e->kv_esz, s);
     if (rc) return rc;
@@ -733,6 +761,7 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     sp.begin_index = e->begin_index; sp.eos = e->eos; sp.pad = e->pad; sp.force_eos_step = e->force_eos_step;
     sp.part_val = e->sel_val; sp.part_idx = e->sel_idx; sp.tok_emb = e->tok_emb; sp.pos_emb = e->pos_emb; sp.next_x = e->dh;
     sp.d_model = e->d; sp.n_parts = 8; sp.fused = 0; sp.emb_half = e->w_half;
+    sp.force_eos_rows = e->force_rows_on ? e->force_rows : nullptr; sp.mailbox = e->mailbox_dev;
     int parts = 0;
     io.argmax = fuse ? &sp : nullptr;
     io.argmax_parts = &parts;
@@ -743,13 +772,9 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     return WT_OK;
 }
 
-extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
-    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_steps: not a decoder engine");
-    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_steps called before wt_decoder_begin");
-    if (n_steps <= 0) return WT_OK;
-    DeviceGuard guard(e->device);
-    HIPCHK(guard.err);
-    hipStream_t s = (hipStream_t)stream;
+// enqueue n_steps decoder steps on `s` (the caller holds the device guard)
+static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s) {
+    e->issued += n_steps;
     if (e->profiling || !e->use_graph) {  // eager: per-kernel event timers need real launches
         for (int i = 0; i < n_steps; ++i) {
             int rc = enqueue_fast_step(e, s);
@@ -772,6 +797,60 @@ extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
         e->graph_valid = true;
     }
     for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(e->graph_exec, s));
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_steps: not a decoder engine");
+    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_steps called before wt_decoder_begin");
+    if (n_steps <= 0) return WT_OK;
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    return enqueue_steps(e, n_steps, (hipStream_t)stream);
+}
+
+// Run the decode in flight to its stop test WITHOUT synchronising the stream per chunk: greedy_finish_kernel reports
+// (epoch, steps retired, done, length, unfinished rows) into a pinned host word after every step, and this loop keeps exactly
+// `lookahead` steps queued behind the one the GPU is running.  The GPU never waits for the host (the next step is already in its
+// queue when one retires) and at most `lookahead` steps are enqueued past the stop -- they are no-ops for the token state but
+// stream the weights, which is what the old "8 steps, then hipStreamSynchronize" loop paid up to 7 times per utterance batch.
+extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_unfinished, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_run: not a decoder engine");
+    if (!e->begun) return fail(WT_E_STATE, "wt_decoder_run called before wt_decoder_begin");
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    hipStream_t s = (hipStream_t)stream;
+    if (lookahead <= 0) lookahead = e->nt_loads ? 1 : 3;   // small models: a step is 0.15-0.3 ms, keep more of them queued
+    if (lookahead > 64) lookahead = 64;
+    const int max_steps = e->max_length - 1;               // MaxLengthCriteria fires at the latest after this many steps
+    unsigned long long mb = 0;
+    long long spins = 0;
+    for (;;) {
+        mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
+        const bool mine = (int)(mb >> 48) == e->epoch;
+        const int retired = mine ? (int)((mb >> 32) & 0xffff) : 0;
+        if (mine && ((mb >> 31) & 1)) break;
+        if (e->issued < max_steps && e->issued - retired <= lookahead) {
+            int rc = enqueue_steps(e, 1, s);
+            if (rc) return rc;
+            spins = 0;
+            continue;
+        }
+        if (e->issued >= max_steps && retired >= e->issued) break;   // every possible step has retired (done is set with the last)
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {   // every ~ms of spinning: is the stream still alive?
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(WT_E_HIP, "wt_decoder_run: stream failed: %s", hipGetErrorString(q));
+            if (q == hipSuccess) {        // idle stream: either the word is about to land, or the steps died without reporting
+                mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
+                const int r2 = (int)(mb >> 48) == e->epoch ? (int)((mb >> 32) & 0xffff) : 0;
+                if (r2 < e->issued && spins > (8ll << 20)) return fail(WT_E_STATE, "wt_decoder_run: %d steps enqueued, %d reported", e->issued, r2);
+            }
+        }
+    }
+    if (cur_len) *cur_len = (int)((mb >> 16) & 0x7fff);
+    if (n_unfinished) *n_unfinished = __builtin_popcountll(mb & 0xffff);
+    for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) timer_collect(*t);
     return WT_OK;
 }
 
@@ -803,14 +882,8 @@ extern "C" int wt_decoder_greedy(wt_engine* e, const float* enc_hidden, int B, c
                                  int* out_len, void* stream) {
     int rc = wt_decoder_begin(e, enc_hidden, B, p, stream);
     if (rc) return rc;
-    int cur = 1, nu = B, done = 0;
-    while (!done) {
-        const int remaining = p->max_length - cur;
-        if (remaining <= 0) break;
-        const int chunk = remaining < 8 ? remaining : 8;  // one host round-trip per 8 tokens (<= 7 wasted steps after the stop)
-        if ((rc = wt_decoder_steps(e, chunk, stream))) return rc;
-        if ((rc = wt_decoder_poll(e, &cur, &nu, &done, stream))) return rc;
-    }
+    int cur = 1, nu = B;
+    if ((rc = wt_decoder_run(e, 0, &cur, &nu, stream))) return rc;
     if (ids_out && (rc = wt_decoder_read_ids(e, ids_out, p->max_length, stream))) return rc;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (out_len) *out_len = cur;

@@ -937,7 +937,14 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
     }
     const int unf = p.unfinished[min(b, p.B - 1)];
     const int done = st->done, cur_len = st->cur_len, step = st->step;
-    if (done) return;   // block-uniform: steps enqueued past the stop test are no-ops
+    if (done) {         // block-uniform: steps enqueued past the stop test are no-ops (the host still sees them retire)
+        if (tid == 0) {
+            const int seq = st->seq + 1;
+            st->seq = seq;
+            if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, 1, cur_len, 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     {
         const int forced = p.forced[cur_len];                          // ForceTokensLogitsProcessor
         float best = -INFINITY;
@@ -971,6 +978,7 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
             if ((unsigned)tok >= (unsigned)p.V) tok = p.eos;      // unreachable with a NaN-aware argmax; never index the embedding out of range
             if (forced >= 0) tok = forced;
             if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
+            if (p.force_eos_rows && step == p.force_eos_rows[b]) tok = p.eos;    // ... per row (variable-length workload)
             if (!unf) tok = p.pad;                                 // finished rows keep emitting pad
             p.ids[(size_t)b * p.max_length + cur_len] = tok;
             if (tok == p.eos) p.unfinished[b] = 0;
@@ -981,14 +989,25 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
     __syncthreads();
     if (tid == 0) {
         int nu = 0;
-        for (int b = 0; b < p.B; ++b) nu += s_unf[b] ? 1 : 0;
+        unsigned unf_mask = 0;
+        for (int b = 0; b < p.B; ++b)
+            if (s_unf[b]) {
+                ++nu;
+                unf_mask |= 1u << b;
+            }
         st->n_unfinished = nu;
         st->cur_len = cur_len + 1;
         st->pos += 1;
         st->self_len += 1;
         st->step = step + 1;
-        if (nu == 0 || cur_len + 1 >= p.max_length) st->done = 1;  // run.py:219-226
+        const int now_done = nu == 0 || cur_len + 1 >= p.max_length;   // run.py:219-226
+        if (now_done) st->done = 1;
+        const int seq = st->seq + 1;
+        st->seq = seq;
         s_pos = st->pos;
+        // progress report for wt_decoder_run: one self-contained 64-bit word, written through to the pinned host page (the ids
+        // themselves are fetched later by a stream-ordered copy, so no release fence -- and no L2 write-back -- is needed here)
+        if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, now_done, cur_len + 1, unf_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     if (!p.next_x || cur_len + 1 >= p.max_length) return;
@@ -1008,7 +1027,7 @@ hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-__global__ void dec_init_kernel(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token) {
+__global__ void dec_init_kernel(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, int epoch) {
     const int t = threadIdx.x;
     if (t == 0) {
         st->cur_len = 1;
@@ -1017,14 +1036,16 @@ __global__ void dec_init_kernel(DecState* st, int* ids, int* unfinished, int B, 
         st->done = max_length <= 1 ? 1 : 0;
         st->n_unfinished = B;
         st->step = 0;
+        st->seq = 0;
+        st->epoch = epoch;
     }
     for (int b = t; b < B; b += blockDim.x) {
         ids[(size_t)b * max_length] = start_token;
         unfinished[b] = 1;
     }
 }
-hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, hipStream_t s) {
-    hipLaunchKernelGGL(dec_init_kernel, dim3(1), dim3(64), 0, s, st, ids, unfinished, B, max_length, start_token);
+hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, int epoch, hipStream_t s) {
+    hipLaunchKernelGGL(dec_init_kernel, dim3(1), dim3(64), 0, s, st, ids, unfinished, B, max_length, start_token, epoch);
     return hipGetLastError();
 }
 
@@ -1035,6 +1056,7 @@ __global__ void set_state_kernel(DecState* st, int cur_len, int pos, int self_le
     st->done = 0;
     st->n_unfinished = 1;
     st->step = 0;
+    st->seq = 0;
 }
 hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s) {
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, cur_len, pos, self_len);

@@ -17,8 +17,17 @@ struct DecState {
     int done;          // stop test fired (all rows EOS, or cur_len >= max_length)
     int n_unfinished;  // rows that have not produced EOS yet
     int step;          // 0-based count of executed steps
-    int pad0, pad1;
+    int seq;           // greedy_finish launches since wt_decoder_begin, no-op ones included (the host mailbox's progress counter)
+    int epoch;         // which wt_decoder_begin this state belongs to (low 16 bits travel in the mailbox word)
 };
+
+// Host mailbox word (64 bits, written by greedy_finish_kernel with ONE system-scope store into pinned host memory after every
+// step, read by wt_decoder_run without touching the stream): [63:48] epoch, [47:32] seq, [31] done, [30:16] cur_len,
+// [15:0] bit b = row b unfinished.
+__host__ __device__ inline unsigned long long mailbox_word(int epoch, int seq, int done, int cur_len, unsigned unfinished_mask) {
+    return ((unsigned long long)(epoch & 0xffff) << 48) | ((unsigned long long)(seq & 0xffff) << 32) |
+           ((unsigned long long)(done ? 1u : 0u) << 31) | ((unsigned long long)(cur_len & 0x7fff) << 16) | (unfinished_mask & 0xffffu);
+}
 
 // ---- fp32 GEMM (encoder / cross-KV):  C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] ) ------------------
 struct GemmParams {
@@ -176,9 +185,11 @@ struct SelectParams {
     int d_model;
     int B, V, max_length, begin_index, eos, pad, force_eos_step;
     int emb_half;          // tok_emb is IEEE half (fp16 decoder engines)
+    const int* force_eos_rows;       // optional [B]: row b emits EOS at 0-based step force_eos_rows[b] (< 0: never) -- bench-only transcript lengths
+    unsigned long long* mailbox;     // optional: device address of the engine's pinned host mailbox (mailbox_word above)
 };
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s);
-hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, hipStream_t s);
+hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, int epoch, hipStream_t s);
 hipError_t launch_copy_cache_rows(const float* src, float* dst, int LH, int src_rows, int dst_rows, int n_rows,
                                   hipStream_t s);
 hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s);

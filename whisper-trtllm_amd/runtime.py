@@ -168,7 +168,7 @@ class WhisperDecoderEngine:
         self.config = config
         self.max_batch = 16   # utterances per engine call (wt_decoder_begin); larger batches are chunked by generate()
 
-    def _params(self, max_length, force_eos_step, logits_trace):
+    def _params(self, max_length, force_eos_step, logits_trace, force_eos_steps=None):
         cfg = self.config
         begin_index = 1 if cfg.get("forced_bos_token_id") is None else 2          # run.py:155-156 with a 1-token prompt
         forced = cfg.get("forced_decoder_ids") or []
@@ -189,16 +189,22 @@ class WhisperDecoderEngine:
             setattr(p, count, n if field != "forced_decoder_ids" else n // 2)
         p.force_eos_step = -1 if force_eos_step is None else force_eos_step
         p.logits_trace = logits_trace.data_ptr() if logits_trace is not None else None
+        if force_eos_steps is not None:           # bench-only per-row transcript lengths
+            arr, _n = _i32_array(force_eos_steps)
+            self._keep.append(arr)
+            p.force_eos_steps = ctypes.cast(arr, ctypes.POINTER(ctypes.c_int32))
         return p
 
-    def begin(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None):
+    def begin(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None, force_eos_steps=None):
         import torch
         i = self.session.info
         if encoder_hidden.dtype != torch.float32 or tuple(encoder_hidden.shape[1:]) != (i.max_source_positions, i.d_model):
             raise ValueError(f"encoder_hidden must be float32 [B,{i.max_source_positions},{i.d_model}]")
         self._enc = encoder_hidden.contiguous()
         self._B = self._enc.shape[0]
-        self._p = self._params(max_length, force_eos_step, logits_trace)
+        if force_eos_steps is not None and len(force_eos_steps) != self._B:
+            raise ValueError(f"force_eos_steps needs one entry per utterance ({self._B}), got {len(force_eos_steps)}")
+        self._p = self._params(max_length, force_eos_step, logits_trace, force_eos_steps)
         self._trace = logits_trace
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(self.session._lib.wt_decoder_begin(self.session.handle, self._enc.data_ptr(), self._B, ctypes.byref(self._p),
@@ -217,6 +223,16 @@ class WhisperDecoderEngine:
                                                       ctypes.c_void_p(stream)), "wt_decoder_poll")
         return cur.value, nu.value, bool(done.value)
 
+    def run(self, lookahead: int = 0):
+        """Drive the decode in flight to its stop test (wt_decoder_run): the host keeps `lookahead` steps queued behind the running
+        one and watches a pinned mailbox word instead of synchronising the stream.  Returns (cur_len, n_unfinished)."""
+        import torch
+        cur, nu = ctypes.c_int(), ctypes.c_int()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.session._lib.wt_decoder_run(self.session.handle, lookahead, ctypes.byref(cur), ctypes.byref(nu),
+                                                     ctypes.c_void_p(stream)), "wt_decoder_run")
+        return cur.value, nu.value
+
     def read_ids(self, cur_len: int):
         import torch
         ml = self._p.max_length
@@ -226,25 +242,29 @@ class WhisperDecoderEngine:
                    "wt_decoder_read_ids")
         return buf[:, :cur_len].clone()
 
-    def generate(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None, chunk: int = 8):
+    def generate(self, encoder_hidden, max_length=None, force_eos_step=None, logits_trace=None, chunk: int = 0, force_eos_steps=None,
+                 lookahead: int = 0):
         """== greedy_search(...) of run.py:171-227 for a batch; returns int32 ids [B, len] on the GPU.
 
-        `chunk` decoder steps are enqueued between two host polls of the stop test: steps enqueued past the stop are
-        no-ops for the token bookkeeping but still stream the weights, so a smaller chunk wastes less work on short
-        transcripts (<= chunk-1 steps) at the price of one ~30 us host round trip per chunk."""
+        Default (`chunk` 0): the stop test is followed through the engine's host mailbox (`run`), at most `lookahead` steps are
+        enqueued past the stop.  `chunk` > 0 selects the older protocol -- `chunk` steps between two synchronising polls."""
         if encoder_hidden.shape[0] > self.max_batch:
             # larger batches run as consecutive engine batches of <= 16 utterances;
             # rows are independent, so the result is the concatenation (shorter groups are right-padded with pad_token_id)
             import torch
             if logits_trace is not None:
                 raise ValueError(f"logits_trace supports at most {self.max_batch} utterances per call")
-            parts = [self.generate(encoder_hidden[i:i + self.max_batch], max_length, force_eos_step, None, chunk)
+            parts = [self.generate(encoder_hidden[i:i + self.max_batch], max_length, force_eos_step, None, chunk,
+                                   None if force_eos_steps is None else force_eos_steps[i:i + self.max_batch], lookahead)
                      for i in range(0, encoder_hidden.shape[0], self.max_batch)]
             width = max(p.shape[1] for p in parts)
             pad = self.config["pad_token_id"]
             parts = [torch.nn.functional.pad(p, (0, width - p.shape[1]), value=pad) for p in parts]
             return torch.cat(parts, dim=0)
-        self.begin(encoder_hidden, max_length, force_eos_step, logits_trace)
+        self.begin(encoder_hidden, max_length, force_eos_step, logits_trace, force_eos_steps)
+        if chunk <= 0:
+            cur, _nu = self.run(lookahead)
+            return self.read_ids(cur)
         cur, done = 1, False
         ml = self._p.max_length
         while not done and cur < ml:

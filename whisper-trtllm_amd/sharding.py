@@ -21,6 +21,27 @@ def batches(begin: int, end: int, batch: int) -> List[Tuple[int, int]]:
     return [(i, min(i + batch, end)) for i in range(begin, end, batch)]
 
 
+def length_sorted_batches(lengths: Sequence[float], batch: int, world: int = 1, rank: int = 0) -> List[List[int]]:
+    """Length-aware batching for real data: a batch decodes until its LONGEST row stops (examples/whisper/run.py:219-226 is batch 1,
+    so the reference never pays for a neighbour), hence utterances of similar length should share a batch.  `lengths` is any
+    monotone proxy of the transcript length -- the audio duration, e.g. `audio.valid_frames(mel)`.  Utterances are sorted by length
+    (descending, ties in dataset order), cut into batches of `batch`, and the batches are dealt round-robin over the ranks so every
+    GPU sees the same mix of long and short batches.  Returns this rank's batches as lists of dataset indices."""
+    if batch < 1 or not (0 <= rank < world):
+        raise ValueError(f"batch {batch}, rank {rank}, world {world}")
+    order = sorted(range(len(lengths)), key=lambda i: (-float(lengths[i]), i))
+    groups = [order[i:i + batch] for i in range(0, len(order), batch)]
+    return groups[rank::world]
+
+
+def slot_utilisation(row_steps: Sequence[int], groups: Sequence[Sequence[int]]) -> float:
+    """Fraction of decoder (row, step) slots that produce a token some row still needs: sum of row lengths / sum over batches of
+    rows x longest row.  1.0 = no row ever waits for a neighbour."""
+    used = sum(int(row_steps[i]) for g in groups for i in g)
+    paid = sum(len(g) * max(int(row_steps[i]) for i in g) for g in groups if len(g))
+    return used / paid if paid else 1.0
+
+
 def max_over_ranks(value: float, dist=None) -> float:
     """bench.py contract: the reported time is the MAX over ranks."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -155,3 +155,27 @@ def make_mel(cfg: dict, index: int, batch: int = 1) -> np.ndarray:
         np.random.default_rng(1000 + index + b).uniform(-1.0, 1.0, (cfg["num_mel_bins"], frames)).astype(np.float32)
         for b in range(batch)
     ])
+
+
+# ---- variable-length workload (bench.py `value_varlen`): LibriSpeech-like utterance durations and transcript lengths ------------------
+PAD_MEL = -1.5   # value of the padding frames behind the audio (below every "speech" value; real features: (max - 8 + 4) / 4, constant)
+
+
+def librispeech_like_lengths(n: int, seed: int = 0, max_length: int = 448):
+    """(durations_s, eos_steps) for `n` utterances.  MODELLED on the published shape of LibriSpeech test-clean (2620 utterances,
+    1.3-35 s, mean 7.4 s; no copy of the dataset exists on either box): duration ~ lognormal(ln 6.2, 0.62) clipped to [1.3, 30] s,
+    transcript = 3.4 BPE tokens per second + the two prompt positions; `eos_steps[i]` is the 0-based decoder step whose token is EOS."""
+    rng = np.random.default_rng([seed, 0x11b5])
+    dur = np.clip(rng.lognormal(np.log(6.2), 0.62, n), 1.3, 30.0)
+    steps = np.clip(np.rint(3.4 * dur).astype(np.int64) + 2, 2, max_length - 2)
+    return dur.astype(np.float64), [int(s) for s in steps]
+
+
+def make_mel_padded(cfg: dict, index: int, duration_s: float) -> np.ndarray:
+    """One synthetic log-mel `[n_mels, frames]`: U(-1,1) over the first duration_s * 100 frames, PAD_MEL behind them -- the shape
+    the front-end gives a clip shorter than the 30 s window (feature_extraction_whisper.py:229-250 pads the WAVEFORM with zeros)."""
+    frames = 2 * cfg["max_source_positions"]
+    valid = max(1, min(frames, int(round(duration_s * 100.0))))
+    mel = np.full((cfg["num_mel_bins"], frames), PAD_MEL, dtype=np.float32)
+    mel[:, :valid] = np.random.default_rng(5000 + index).uniform(-1.0, 1.0, (cfg["num_mel_bins"], valid)).astype(np.float32)
+    return mel
