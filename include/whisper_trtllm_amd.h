@@ -173,12 +173,13 @@ int wt_decoder_time_kernel(wt_engine* dec, const char* which, int iters, float* 
 
 /* ---- log-mel front-end: replaces the CPU numpy STFT inside the reference's timed loop,
  * `hf_processor(sample["array"], ...)` run.py:267 == WhisperFeatureExtractor._np_extract_fbank_features
- * (transformers/models/whisper/feature_extraction_whisper.py:94-111).  The host passes the constant tables:
- * dft f32 [ndft][n_fft] (rows 0..n_bins-1 = cos, rows ndft/2 .. ndft/2+n_bins-1 = -sin, other rows 0), the Hann
- * window [n_fft] and the mel filter bank [n_mels][npw] (columns >= n_bins zero). */
+ * (transformers/models/whisper/feature_extraction_whisper.py:94-111).  The host passes the Hann window as fp64 [n_fft] (the
+ * reference frames in float64, audio_utils.py:399-401) and the mel filter bank f32 [n_mels][npw] (columns >= n_bins zero, npw =
+ * n_bins rounded up to a multiple of 4); the fp64 DFT matrix is built inside.  Windowed DFT and power spectrum run in fp64
+ * (v_mfma_f64_16x16x4_f64), like the reference's float64 rfft; features agree with it to ~1e-6. */
 typedef struct wt_logmel wt_logmel;
-int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int n_frames, const float* dft, int ndft, const float* window,
-                     const float* filters, int npw, wt_logmel** out);
+int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int n_frames, const double* window, const float* filters, int npw,
+                     wt_logmel** out);
 void wt_logmel_destroy(wt_logmel* h);
 /* audio f32 [batch][n_in] on the device (n_in samples each; shorter than 30 s = zero-padded, longer = trimmed)
  * -> mel_out f32 [batch][n_mels][n_frames].  Asynchronous on `stream`. */

@@ -58,8 +58,9 @@ def test_oracle_frontend_matches_reference(gold, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_gpu_frontend_matches_oracle_and_reference(gold, case):
-    """fp32 MFMA DFT vs the reference's float64 rfft: features agree to 2e-3 abs (clamped range is 2.0 wide);
-    the bulk (99%) agrees to 2e-4.  Spectral-leakage-floor bins carry the fp32 rounding of a 400-term DFT."""
+    """fp64 MFMA DFT (v_mfma_f64_16x16x4_f64) vs the reference's float64 rfft: features agree to 2e-5 abs (VERDICT r2's bar;
+    measured ~1e-6: what is left is the fp32 mel projection and log10), including the spectral-leakage-floor bins that an fp32
+    DFT missed by up to 2e-3 in round 2."""
     import whisper_trtllm_amd as wt
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible")
@@ -69,9 +70,9 @@ def test_gpu_frontend_matches_oracle_and_reference(gold, case):
     ref = cpu_ref.log_mel_spectrogram(wav)
     assert got.shape == (80, 3000) and np.isfinite(got).all()
     err = np.abs(got - ref)
-    assert err.max() < 2e-3, err.max()
-    assert np.quantile(err, 0.99) < 2e-4, np.quantile(err, 0.99)
-    np.testing.assert_allclose(got[::5, ::37], gold[f"{case}_sub"], atol=2e-3)
+    assert err.max() < 2e-5, err.max()
+    assert np.quantile(err, 0.99) < 2e-6, np.quantile(err, 0.99)
+    np.testing.assert_allclose(got[::5, ::37], gold[f"{case}_sub"], atol=2e-5)
 
 
 @pytest.mark.gpu
@@ -82,7 +83,7 @@ def test_gpu_frontend_batched_and_feeds_the_encoder():
     mel = fe(torch.from_numpy(wavs).cuda())
     assert tuple(mel.shape) == (3, 80, 3000)
     for i in range(3):
-        np.testing.assert_allclose(mel[i].cpu().numpy(), cpu_ref.log_mel_spectrogram(wavs[i]), atol=2e-3)
+        np.testing.assert_allclose(mel[i].cpu().numpy(), cpu_ref.log_mel_spectrogram(wavs[i]), atol=2e-5)
     cfg = wt.synthetic.get_config("toy")
     enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, wt.synthetic.make_weights(cfg, 2)))
     hidden = enc(mel)
@@ -91,11 +92,12 @@ def test_gpu_frontend_batched_and_feeds_the_encoder():
 
 @pytest.mark.gpu
 def test_waveform_to_token_ids_end_to_end():
-    """waveform -> GPU log-mel -> encoder -> greedy decode, against the same chain on the CPU oracle.  The front-end's
-    fp32-vs-fp64 difference (<= 2e-3 on clamped features) must not move the encoder memory by more than 1e-2 of its range."""
+    """waveform -> GPU log-mel -> encoder -> greedy decode, against the same chain on the CPU oracle: ids equal, unconditionally.
+    Weight seed 17 pins the oracle's minimum top-2 margin at 2.4e-2 on these two waveforms (seeds 9..18 searched with the oracle:
+    2.3e-4 .. 2.4e-2); a margin below 1e-3 FAILS the test instead of skipping the comparison."""
     import whisper_trtllm_amd as wt
     cfg = wt.synthetic.get_config("toy")               # 1500-frame encoder memory, i.e. real 30 s inputs
-    weights = wt.synthetic.make_weights(cfg, 9)
+    weights = wt.synthetic.make_weights(cfg, 17)
     wavs = np.stack([synthetic_waveform(20 + i, 30.0) for i in range(2)])
     fe = wt.audio.LogMelFrontend()
     enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights))
@@ -107,11 +109,11 @@ def test_waveform_to_token_ids_end_to_end():
     with torch.no_grad():
         h_ref = cpu_ref.encoder_forward(W, cfg, mel_ref)
         ids_ref, logits_ref = cpu_ref.greedy_search(W, cfg, h_ref, return_logits=True)
-    assert (hidden.cpu() - h_ref).abs().max().item() < 1e-2 * h_ref.abs().max().item()
-    top2 = torch.topk(logits_ref, 2, dim=-1).values
-    if (top2[..., 0] - top2[..., 1]).min().item() > 5e-2:   # only compare ids when the oracle's choices are clear-cut
-        np.testing.assert_array_equal(ids, ids_ref.numpy())
-    assert ids.shape == tuple(ids_ref.shape)
+    assert (hidden.cpu() - h_ref).abs().max().item() < 1e-4 * h_ref.abs().max().item()
+    margin = torch.topk(logits_ref, 2, dim=-1).values
+    margin = (margin[..., 0] - margin[..., 1])[:, 1:]          # step 0 is the forced token
+    assert margin.min().item() > 1e-3, "the pinned seed lost its margin: re-run the seed search"
+    np.testing.assert_array_equal(ids, ids_ref.numpy())
 
 
 @pytest.mark.gpu

@@ -92,7 +92,7 @@ def load():
     lib.wt_decoder_greedy.argtypes = [c_void_p, c_void_p, c_int, POINTER(GreedyParams), c_void_p, POINTER(c_int), c_void_p]
     lib.wt_engine_set_profiling.argtypes = [c_void_p, c_int]
     lib.wt_engine_get_timer.argtypes = [c_void_p, c_char_p, POINTER(KernelTimer)]
-    lib.wt_logmel_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p)]
+    lib.wt_logmel_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p)]
     lib.wt_logmel_destroy.argtypes = [c_void_p]
     lib.wt_logmel_destroy.restype = None
     lib.wt_logmel_forward.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]

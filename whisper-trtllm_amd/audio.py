@@ -2,7 +2,8 @@
 
 Replaces `hf_processor(audio, sampling_rate=..., return_tensors="pt").input_features` in the reference's timed loop
 (examples/whisper/run.py:267), i.e. WhisperFeatureExtractor (feature_extraction_whisper.py:84-111, audio_utils.py:115-190,
-206-264, 267-452).  The tables are computed here in float64 and handed to the C-ABI as fp32."""
+206-264, 267-452).  The Hann window goes to the C-ABI in float64 (the DFT runs in fp64 on the matrix cores, like the reference's
+float64 rfft), the mel filter bank in fp32; `dft_tables` is the fp32 real-DFT matrix kept for host-side checks."""
 from __future__ import annotations
 
 import ctypes
@@ -82,15 +83,14 @@ class LogMelFrontend:
         if not torch.cuda.is_available():
             raise RuntimeError("LogMelFrontend needs a ROCm GPU; there is no CPU execution path")
         dev = torch.cuda.current_device() if device is None else device
-        dft, ndft = dft_tables()
         n_bins = N_FFT // 2 + 1
         npw = (n_bins + 3) // 4 * 4
         filt = np.zeros((N_MELS, npw), dtype=np.float32)
         filt[:, :n_bins] = mel_filter_bank().T.astype(np.float32)
-        win = hann_window().astype(np.float32)
+        win = np.ascontiguousarray(hann_window(), dtype=np.float64)   # the reference frames in float64 (audio_utils.py:399-401)
         self._handle = ctypes.c_void_p()
-        _lib.check(self._lib.wt_logmel_create(dev, N_FFT, HOP, N_MELS, N_FRAMES, dft.ctypes.data, ndft, win.ctypes.data,
-                                              filt.ctypes.data, npw, ctypes.byref(self._handle)), "wt_logmel_create")
+        _lib.check(self._lib.wt_logmel_create(dev, N_FFT, HOP, N_MELS, N_FRAMES, win.ctypes.data, filt.ctypes.data, npw,
+                                              ctypes.byref(self._handle)), "wt_logmel_create")
 
     def __call__(self, waveforms):
         import torch

@@ -2,8 +2,8 @@
 // Reference: HF WhisperFeatureExtractor._np_extract_fbank_features (feature_extraction_whisper.py:94-111) over
 // audio_utils.spectrogram (audio_utils.py:267-452): zero-pad/trim to 30 s, reflect-pad 200, Hann-400 frames with hop 160,
 // |rfft|^2, slaney mel filter bank (80 x 201), log10(max(1e-10, .)), drop the last frame, clamp to max-8, (x+4)/4.
-// The DFT and the mel projection are dense contractions and run on the fp32 MFMA GEMM (gemm_f32_kernel); framing,
-// power, log/max and the normalising transpose are small coalesced kernels.
+// Framing + windowed DFT + power run in fp64 on the matrix cores (dft_power_f64_kernel), the mel projection on the fp32 MFMA GEMM
+// (gemm_f32_kernel); log/max and the normalising transpose are small coalesced kernels.
 #include "../../include/whisper_trtllm_amd.h"
 #include "wt_common.h"
 
@@ -11,49 +11,108 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+#include <vector>
+
 using namespace wt;
 
 int wt_set_error(int code, const char* fmt, ...);  // engine.hip
 
 struct wt_logmel {
     int device = 0, n_fft = 0, hop = 0, n_mels = 0, n_frames = 0, n_bins = 0, n_samples = 0;
-    int ndft = 0, npw = 0;   // padded widths: DFT output columns (re|pad|im|pad), power columns
-    float *dft = nullptr, *window = nullptr, *filt = nullptr;
+    int npw = 0, nbt = 0;    // power columns (n_bins rounded up to 4), 16-bin tiles of the DFT
+    double *frag = nullptr, *window = nullptr;   // fp64 DFT matrix in MFMA fragment order, fp64 Hann window
+    float* filt = nullptr;
     int cap = 0;
-    float *frames = nullptr, *spec = nullptr, *pw = nullptr, *mel = nullptr, *bmax = nullptr;
+    float *pw = nullptr, *mel = nullptr, *bmax = nullptr;
 };
 
-// frames[(b*T + t)][j] = padded[t*hop + j] * window[j]; padded = reflect-pad(n_fft/2) of the zero-padded/trimmed waveform
-__global__ __launch_bounds__(256) void frame_window_kernel(const float* __restrict__ audio, int n_in, int n_samples,
-                                                           const float* __restrict__ window, float* __restrict__ frames,
-                                                           int T, int n_fft, int hop) {
-    const int t = blockIdx.x, b = blockIdx.y;
-    const float* x = audio + (size_t)b * n_in;
-    float* out = frames + ((size_t)b * T + t) * n_fft;
-    const int half = n_fft / 2;
-    for (int j = threadIdx.x; j < n_fft; j += 256) {
-        int i = t * hop + j - half;                 // index into the 30 s signal
-        if (i < 0) i = -i;                          // np.pad(mode="reflect")
-        if (i >= n_samples) i = 2 * (n_samples - 1) - i;
-        const float v = i < n_in ? x[i] : 0.f;      // zero padding up to 30 s
-        out[j] = v * window[j];
-    }
-}
+// ---- windowed DFT + power spectrum in fp64 on the matrix cores ----------------------------------------------------------------
+// The reference frames the waveform in float64, takes np.fft.rfft in float64, stores the spectrum as complex64 and squares its
+// magnitude in float64 (audio_utils.py:399-428).  Bins on the spectral-leakage floor are sums of 400 products that cancel to
+// ~1e-7 of their terms, so an fp32 DFT misses them by up to 2e-3 of the feature range (round 2); v_mfma_f64_16x16x4_f64 makes the
+// DFT exact to fp64 rounding at 8 GFLOP per 8 x 30 s -- ~0.2 ms of the chip's fp64 matrix rate.
+//   grid (ceil(T / 64), batch); 4 waves: wave = (frame group of 32) x (half of the bin tiles).  The block's 63*hop + n_fft samples
+//   sit in LDS as fp32, the A fragment a[frame][k] = (double)x[frame*hop + k] * window[k] is formed in registers; the DFT matrix
+//   is pre-laid in fragment order (tile n = 2*bin_tile + {cos, -sin}, k-step, lane), so a B fragment is one coalesced 512-byte load
+//   from L2 (1.3 MB in all) feeding two MFMAs.  cos and -sin tiles of the same bins land in the same lane and register, so
+//   |X|^2 = fl32(re)^2 + fl32(im)^2 (the reference's complex64 rounding) needs no exchange.
+// Fragment maps (cdna guide: f64 MFMA): A row = lane & 15, k = lane >> 4; B col = lane & 15, k = lane >> 4;
+// C/D col = lane & 15, row = (lane >> 4) + 4 * reg.
+typedef double d4v __attribute__((ext_vector_type(4)));
+constexpr int DFT_FRAMES = 64;       // frames per workgroup
+constexpr int DFT_MAX_BT = 7;        // bin tiles per wave half (n_fft <= 446)
 
-// pw[m][f] = re^2 + im^2 for f < n_bins (re at column f, im at column im_off + f of spec); padding columns = 0
-__global__ __launch_bounds__(256) void power_kernel(const float* __restrict__ spec, float* __restrict__ pw, size_t rows,
-                                                    int ndft, int npw, int n_bins, int im_off) {
-    const size_t total = rows * npw;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t m = i / npw;
-        const int f = (int)(i - m * npw);
-        float v = 0.f;
-        if (f < n_bins) {
-            const float re = spec[m * ndft + f], im = spec[m * ndft + im_off + f];
-            v = re * re + im * im;
-        }
-        pw[i] = v;
+__global__ __launch_bounds__(256) void dft_power_f64_kernel(const float* __restrict__ audio, int n_in, int n_samples,
+                                                            const double* __restrict__ window, const double* __restrict__ frag,
+                                                            float* __restrict__ pw, int T, int n_fft, int hop, int npw, int nbt) {
+    extern __shared__ __attribute__((aligned(16))) double dft_smem[];
+    double* s_w = dft_smem;                                        // [n_fft]
+    float* s_x = reinterpret_cast<float*>(dft_smem + n_fft);       // [(DFT_FRAMES - 1) * hop + n_fft]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fg = wave & 1, half = wave >> 1;
+    const int b = blockIdx.y, t0 = blockIdx.x * DFT_FRAMES;
+    const int span = (DFT_FRAMES - 1) * hop + n_fft, ksteps = n_fft >> 2;
+    const float* x = audio + (size_t)b * n_in;
+    for (int i = tid; i < span; i += 256) {
+        long long sidx = (long long)t0 * hop + i - n_fft / 2;     // index into the 30 s signal
+        if (sidx < 0) sidx = -sidx;                               // np.pad(mode="reflect")
+        if (sidx >= n_samples) sidx = 2ll * (n_samples - 1) - sidx;
+        s_x[i] = (sidx >= 0 && sidx < n_in) ? x[sidx] : 0.f;      // zero padding up to 30 s (and frames past T in the last block)
     }
+    for (int i = tid; i < n_fft; i += 256) s_w[i] = window[i];
+    __syncthreads();
+    const int bt_mid = (nbt + 1) >> 1;
+    const int bt0 = half ? bt_mid : 0, nb = half ? nbt - bt_mid : bt_mid;   // this wave's bin tiles [bt0, bt0 + nb)
+    d4v acc[2][2 * DFT_MAX_BT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 2 * DFT_MAX_BT; ++j) acc[r][j] = d4v{0.0, 0.0, 0.0, 0.0};
+    const int frow = fg * 32 + (lane & 15), kl = lane >> 4;
+    const double* fp = frag + (size_t)(2 * bt0) * ksteps * 64 + lane;
+    // B fragments of k-step kk + 1 are requested before the MFMAs of step kk (two static register sets): the L2 round trip hides
+    // under 2 * 2 * nb MFMAs of 64 clocks each
+    double bq[2][2 * DFT_MAX_BT];
+    auto bload = [&](auto set_c, const int kk) {
+        constexpr int set = decltype(set_c)::value;
+#pragma unroll
+        for (int j = 0; j < 2 * DFT_MAX_BT; ++j)
+            if (j < 2 * nb) bq[set][j] = fp[((size_t)j * ksteps + kk) * 64];
+    };
+    auto kstep = [&](auto set_c, const int kk) {
+        constexpr int set = decltype(set_c)::value;
+        if (kk + 1 < ksteps) bload(std::integral_constant<int, set ^ 1>{}, kk + 1);
+        const int k = kk * 4 + kl;
+        const double wv = s_w[k];
+        const double a0 = (double)s_x[frow * hop + k] * wv;
+        const double a1 = (double)s_x[(frow + 16) * hop + k] * wv;
+#pragma unroll
+        for (int j = 0; j < 2 * DFT_MAX_BT; ++j)
+            if (j < 2 * nb) {   // wave-uniform
+                acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bq[set][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bq[set][j], acc[1][j], 0, 0, 0);
+            }
+    };
+    bload(std::integral_constant<int, 0>{}, 0);
+    for (int kk = 0; kk < ksteps; kk += 2) {
+        kstep(std::integral_constant<int, 0>{}, kk);
+        if (kk + 1 < ksteps) kstep(std::integral_constant<int, 1>{}, kk + 1);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < DFT_MAX_BT; ++q)
+            if (q < nb) {
+                const int bin = (bt0 + q) * 16 + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float re = (float)acc[r][2 * q][i], im = (float)acc[r][2 * q + 1][i];   // complex64 storage of the reference
+                    const double pwr = (double)re * (double)re + (double)im * (double)im;
+                    const int t = t0 + fg * 32 + r * 16 + (lane >> 4) + 4 * i;
+                    if (t < T && bin < npw) pw[((size_t)b * T + t) * npw + bin] = (float)pwr;
+                }
+            }
 }
 
 // mel[m][c] -> log10(max(1e-10, mel)) in place + per-block maximum (one block = 64 frames of one utterance)
@@ -99,31 +158,50 @@ __global__ __launch_bounds__(256) void normalize_transpose_kernel(const float* _
     }
 }
 
-extern "C" int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int n_frames, const float* dft, int ndft,
-                                const float* window, const float* filters, int npw, wt_logmel** out) {
-    if (!out || !dft || !window || !filters) return wt_set_error(WT_E_INVALID, "wt_logmel_create: null argument");
+extern "C" int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int n_frames, const double* window,
+                                const float* filters, int npw, wt_logmel** out) {
+    if (!out || !window || !filters) return wt_set_error(WT_E_INVALID, "wt_logmel_create: null argument");
     *out = nullptr;
-    const int n_bins = n_fft / 2 + 1;
-    if (n_fft <= 0 || (n_fft & 3) || hop <= 0 || n_mels <= 0 || n_mels > 128 || n_frames <= 0 || ndft < 2 * n_bins || (ndft & 1) ||
-        npw < n_bins || (npw & 3))
-        return wt_set_error(WT_E_INVALID, "wt_logmel_create: bad geometry (n_fft %d hop %d n_mels %d frames %d ndft %d npw %d)", n_fft, hop,
-                            n_mels, n_frames, ndft, npw);
+    const int n_bins = n_fft / 2 + 1, nbt = (n_bins + 15) / 16;
+    if (n_fft <= 0 || (n_fft & 3) || hop <= 0 || n_mels <= 0 || n_mels > 128 || n_frames <= 0 || npw < n_bins || (npw & 3) ||
+        npw > nbt * 16 || nbt > 2 * DFT_MAX_BT || (size_t)n_fft * 8 + ((size_t)(DFT_FRAMES - 1) * hop + n_fft) * 4 > 160 * 1024)
+        return wt_set_error(WT_E_INVALID, "wt_logmel_create: bad geometry (n_fft %d hop %d n_mels %d frames %d npw %d)", n_fft, hop,
+                            n_mels, n_frames, npw);
     wt::DeviceGuard guard(device);
     if (guard.err != hipSuccess) return wt_set_error(WT_E_HIP, "hipSetDevice(%d) failed", device);
     wt_logmel* h = new wt_logmel();
     h->device = device; h->n_fft = n_fft; h->hop = hop; h->n_mels = n_mels; h->n_frames = n_frames; h->n_bins = n_bins;
-    h->n_samples = n_frames * hop; h->ndft = ndft; h->npw = npw;
-    const size_t nd = (size_t)ndft * n_fft, nf = (size_t)n_mels * npw;
-    if (hipMalloc((void**)&h->dft, nd * 4) != hipSuccess || hipMalloc((void**)&h->window, (size_t)n_fft * 4) != hipSuccess ||
+    h->n_samples = n_frames * hop; h->npw = npw; h->nbt = nbt;
+    // real-input DFT matrix in fp64, in the fragment order of dft_power_f64_kernel: tile n = 2 * bin_tile + part (0: cos, 1: -sin),
+    // k-step kk, lane l  ->  row (bin) = 16 * bin_tile + (l & 15), column (sample) = 4 * kk + (l >> 4); bins >= n_bins are zero rows
+    const int ksteps = n_fft / 4;
+    const size_t nfrag = (size_t)2 * nbt * ksteps * 64, nf = (size_t)n_mels * npw;
+    std::vector<double> frag(nfrag, 0.0);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n = 0; n < 2 * nbt; ++n)
+        for (int kk = 0; kk < ksteps; ++kk)
+            for (int l = 0; l < 64; ++l) {
+                const int bin = 16 * (n >> 1) + (l & 15), k = 4 * kk + (l >> 4);
+                if (bin >= n_bins) continue;
+                const double ang = two_pi * (double)(((long long)bin * k) % n_fft) / (double)n_fft;
+                frag[((size_t)n * ksteps + kk) * 64 + l] = (n & 1) ? -sin(ang) : cos(ang);
+            }
+    if (hipMalloc((void**)&h->frag, nfrag * 8) != hipSuccess || hipMalloc((void**)&h->window, (size_t)n_fft * 8) != hipSuccess ||
         hipMalloc((void**)&h->filt, nf * 4) != hipSuccess) {
         wt_logmel_destroy(h);  // frees whichever tables were already allocated
         return wt_set_error(WT_E_NOMEM, "wt_logmel_create: table allocation failed");
     }
-    if (hipMemcpy(h->dft, dft, nd * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->window, window, (size_t)n_fft * 4, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(h->frag, frag.data(), nfrag * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->window, window, (size_t)n_fft * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->filt, filters, nf * 4, hipMemcpyHostToDevice) != hipSuccess) {
         wt_logmel_destroy(h);
         return wt_set_error(WT_E_HIP, "wt_logmel_create: table upload failed");
+    }
+    const int smem = n_fft * 8 + ((DFT_FRAMES - 1) * hop + n_fft) * 4;
+    if (smem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dft_power_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        wt_logmel_destroy(h);
+        return wt_set_error(WT_E_HIP, "wt_logmel_create: cannot reserve %d bytes of LDS", smem);
     }
     *out = h;
     return WT_OK;
@@ -132,7 +210,7 @@ extern "C" int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int 
 extern "C" void wt_logmel_destroy(wt_logmel* h) {
     if (!h) return;
     wt::DeviceGuard guard(h->device);
-    for (float* p : {h->dft, h->window, h->filt, h->frames}) if (p) hipFree(p);
+    for (void* p : {(void*)h->frag, (void*)h->window, (void*)h->filt, (void*)h->pw}) if (p) hipFree(p);
     delete h;
 }
 
@@ -145,27 +223,23 @@ extern "C" int wt_logmel_forward(wt_logmel* h, const float* audio, int batch, in
     const size_t M = (size_t)batch * T;
     const int nblk = (T + 63) / 64;
     if (batch > h->cap) {
-        if (h->frames) hipFree(h->frames);
-        const size_t floats = M * h->n_fft + M * h->ndft + M * h->npw + M * h->n_mels + (size_t)batch * nblk + 64;
-        if (hipMalloc((void**)&h->frames, floats * 4) != hipSuccess) {
-            h->frames = nullptr; h->cap = 0;
+        if (h->pw) hipFree(h->pw);
+        const size_t floats = M * h->npw + M * h->n_mels + (size_t)batch * nblk + 64;
+        if (hipMalloc((void**)&h->pw, floats * 4) != hipSuccess) {
+            h->pw = nullptr; h->cap = 0;
             return wt_set_error(WT_E_NOMEM, "wt_logmel_forward: workspace allocation (%zu bytes) failed", floats * 4);
         }
-        h->spec = h->frames + M * h->n_fft;
-        h->pw = h->spec + M * h->ndft;
         h->mel = h->pw + M * h->npw;
         h->bmax = h->mel + M * h->n_mels;
         h->cap = batch;
     }
-    hipLaunchKernelGGL(frame_window_kernel, dim3(T, batch), dim3(256), 0, s, audio, n_in, h->n_samples, h->window, h->frames, T,
-                       h->n_fft, h->hop);
+    const int smem = h->n_fft * 8 + ((DFT_FRAMES - 1) * h->hop + h->n_fft) * 4;
+    hipLaunchKernelGGL(dft_power_f64_kernel, dim3((T + DFT_FRAMES - 1) / DFT_FRAMES, batch), dim3(256), smem, s, audio, n_in, h->n_samples,
+                       h->window, h->frag, h->pw, T, h->n_fft, h->hop, h->npw, h->nbt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return wt_set_error(WT_E_HIP, "DFT kernel launch failed: %s", hipGetErrorString(e));
+    // mel projection: 201-term sums of non-negative products -- no cancellation, the fp32 MFMA GEMM is within 1e-6 relative
     GemmParams g;
-    memset(&g, 0, sizeof g);
-    g.A = h->frames; g.lda = h->n_fft; g.a_rows_per_batch = (int)M; g.W = h->dft; g.M = (int)M; g.N = h->ndft; g.K = h->n_fft;
-    g.C = h->spec; g.ldc = h->ndft; g.c_rows_per_batch = (int)M;
-    hipError_t e = launch_gemm_f32(g, s);
-    if (e != hipSuccess) return wt_set_error(WT_E_HIP, "DFT GEMM launch failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(power_kernel, dim3(2048), dim3(256), 0, s, h->spec, h->pw, M, h->ndft, h->npw, h->n_bins, h->ndft / 2);
     memset(&g, 0, sizeof g);
     g.A = h->pw; g.lda = h->npw; g.a_rows_per_batch = (int)M; g.W = h->filt; g.M = (int)M; g.N = h->n_mels; g.K = h->npw;
     g.C = h->mel; g.ldc = h->n_mels; g.c_rows_per_batch = (int)M;

@@ -941,7 +941,9 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p
         if (tid == 0) {
             const int seq = st->seq + 1;
             st->seq = seq;
-            if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, 1, cur_len, 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned unf_mask = 0;   // unchanged since the stop: the host may read this word instead of the stopping step's
+            for (int r = 0; r < p.B; ++r) unf_mask |= p.unfinished[r] ? 1u << r : 0u;
+            if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, 1, cur_len, unf_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
