@@ -58,6 +58,40 @@ def bench_dec_attn(B=8, H=16, S=1500, L=24):
             print(f"dec_attn len={length} (cap {S}) n_split={ns}: {us:7.2f} us")
 
 
+def bench_self_attn_tail(H=16, S=448, L=24):
+    """VERDICT r2 item 3 (self-attention fused into the q|k|v GEMV by a last-arriver ticket per head): the tail would run on 16
+    workgroups (one per head), each streaming that head's K/V of ALL B rows.  Emulation: the stand-alone kernel at B = 1 puts
+    exactly 16 workgroups on the chip, one (row, head) each -- the fused tail costs about B x its streaming time."""
+    d = 64 * H
+    for B in (1, 8):
+        q = torch.randn(B, d, device="cuda") * 0.3
+        k = torch.randn(L, B, H, S, 64, device="cuda")
+        v = torch.randn(L, B, H, S, 64, device="cuda")
+        out = torch.empty(B, d, device="cuda")
+        cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+        part = torch.empty(B, H, 1, 68, device="cuda")
+        for length in (8, 32, 96, 224, 447):
+            us = timeit(lambda i: lib.wt_dbg_decode_attention(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), B, H, S, length, 1, ST()), L)
+            print(f"self-attention B={B} ({B * H} workgroups) len={length}: {us:6.2f} us")
+
+
+def bench_dec_attn_f16(H=16, S=1500, L=24):
+    """cross-attention over fp16 resident caches (fp16 decoder engines): batch 8 / 16, key splits 1 / 2 / 4; WT_ATTN_U_HALF = keys per
+    stream and iteration (WT_TUNING=1)"""
+    d = 64 * H
+    for B in (8, 16):
+        q = torch.randn(B, d, device="cuda") * 0.3
+        k = (torch.randn(L, B, H, S, 64, device="cuda") * 0.5).half()
+        v = (torch.randn(L, B, H, S, 64, device="cuda") * 0.5).half()
+        out = torch.empty(B, d, device="cuda")
+        cnt = torch.zeros(B, H, dtype=torch.int32, device="cuda")
+        mb = B * H * S * 64 * 2 * 2 / 1e6
+        for ns in (1, 2, 4):
+            part = torch.empty(B, H, ns, 68, device="cuda")
+            us = timeit(lambda i: lib.wt_dbg_decode_attention_f16(P(q), P(k[i]), P(v[i]), P(part), P(cnt), P(out), None, None, None, B, H, S, S, ns, ST()), L)
+            print(f"dec_attn f16 B={B} S={S} n_split={ns}: {us:7.2f} us  {mb / us:6.2f} TB/s  ({mb / us / 8:.3f} of 8 TB/s)")
+
+
 def bench_dec_attn_folded(B=8, H=16, S=1500, L=24):
     """cross-attention launch with the plain query vs the folded query (LayerNorm statistics finished in the kernel)"""
     d = H * 64
@@ -106,6 +140,19 @@ def bench_gemm(M=12000):
         C = torch.empty(M, N, device="cuda")
         us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, ST()), 4, iters=3)
         print(f"gemm M={M} N={N} K={K} act={act}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+
+
+def bench_gemm_shapes():
+    """fp32 GEMM on the encoder shapes of medium.en / small.en (batch 8) and tiny.en (batch 1); run once per WT_GEMM_BN setting"""
+    for (M, N, K) in ((12000, 1024, 1024), (12000, 1024, 4096), (12000, 2048, 1024), (12000, 3072, 1024), (12000, 4096, 1024),
+                      (12000, 768, 768), (12000, 768, 3072), (12000, 2304, 768), (12000, 3072, 768), (12000, 1536, 768),
+                      (1500, 384, 384), (1500, 1152, 384), (1500, 1536, 384), (1500, 384, 1536)):
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(4, N, K, device="cuda") * 0.03
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, 0, ST()), 4, iters=10)
+        print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
 def bench_gemm_fixed(M=12000, N=1024):

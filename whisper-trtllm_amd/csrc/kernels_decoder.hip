@@ -622,7 +622,10 @@ __device__ __forceinline__ float row8_allreduce_sum(float v) {   // sum over eac
     v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
     return v;
 }
-template <int U, bool NT, bool KVH>
+// PIPE: the U keys a stream takes per iteration are handled as two half-tiles with their own registers; the loads of one half are in
+// flight while the other is consumed (the same number of loads in flight as the plain form, but the exp / FMA work of a half-tile --
+// a fifth of an iteration with fp16 caches, a tenth with fp32 -- no longer sits between one tile's arrival and the next request).
+template <int U, bool NT, bool KVH, bool PIPE = false>
 __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     constexpr int LPK = KVH ? 8 : 16;          // lanes per key
     constexpr int DPL = HEAD_DIM / LPK;        // head dims per lane: 8 or 4 (16 bytes of K or V either way)
@@ -672,7 +675,28 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     // the first K/V tile is requested before the query prologue, whose loads and reductions then hide under its latency
     const int s_first = s_begin + sid;
     f4v kk[U], vv[U];
-    if (s_first < s_end) load_tile(kk, vv, s_first);
+    constexpr int UH = PIPE ? U / 2 : U;       // keys per stream and half-tile
+    auto load_half = [&](const int h, const int s0) {   // half-tile h = registers [h * UH, (h + 1) * UH); unconditional clamped loads
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            const size_t key = (size_t)min(s0 + NSTR * u, s_end - 1) * (HEAD_DIM * KSZ);
+            if (NT) {
+                kk[h * UH + u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(kb + key));
+                vv[h * UH + u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vb + key));
+            } else {
+                kk[h * UH + u] = *reinterpret_cast<const f4v*>(kb + key);
+                vv[h * UH + u] = *reinterpret_cast<const f4v*>(vb + key);
+            }
+        }
+    };
+    if constexpr (PIPE) {
+        if (s_begin < s_end) {   // block-uniform; clamping keeps every address inside this block's keys
+            load_half(0, s_first);
+            load_half(1, s_first + NSTR * UH);
+        }
+    } else {
+        if (s_first < s_end) load_tile(kk, vv, s_first);
+    }
 
     float q[DPL];
 #pragma unroll
@@ -719,14 +743,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     float acc[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
-    for (int s0 = s_first; s0 < s_end; s0 += NSTR * U) {  // (a register double buffer of the tiles measured 0.5-1 us SLOWER per launch)
-        if (s0 != s_first) load_tile(kk, vv, s0);
-        float sc[U];
+    auto consume = [&](const int h, const int s0) {   // online-softmax update with the UH keys of half-tile h (first key s0 < s_end)
+        float sc[UH];
         float mx = m;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UH; ++u) {
             float kf[DPL];
-            widen(kk[u], kf);
+            widen(kk[h * UH + u], kf);
             float dot = q[DPL - 1] * kf[DPL - 1];
 #pragma unroll
             for (int i = DPL - 2; i >= 0; --i) dot = fmaf(q[i], kf[i], dot);
@@ -734,21 +757,53 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
             if (s0 + NSTR * u >= s_end) sc[u] = -INFINITY;
             mx = fmaxf(mx, sc[u]);
         }
-        // s0 < s_end, so u = 0 is always a real key and mx is finite here
-        const float alpha = __expf(m - mx);
+        // plain form: s0 < s_end, so u = 0 is a real key and mx is finite.  PIPE consumes branch-free (a skipped consumer would make
+        // the waitcnt pass merge "loads pending" with "loads waited for" and drain vmcnt(0) in front of every request): a stream
+        // past its last key has every score at -inf, keeps m, and rescales by exp(0) -- or by 0 while it has seen no key at all.
+        const float mxs = PIPE && mx == -INFINITY ? 0.f : mx;
+        const float alpha = __expf(m - mxs);
         l *= alpha;
 #pragma unroll
         for (int i = 0; i < DPL; ++i) acc[i] *= alpha;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float pr = __expf(sc[u] - mx);
+        for (int u = 0; u < UH; ++u) {
+            const float pr = __expf(sc[u] - mxs);
             l += pr;
             float vf[DPL];
-            widen(vv[u], vf);
+            widen(vv[h * UH + u], vf);
 #pragma unroll
             for (int i = 0; i < DPL; ++i) acc[i] = fmaf(pr, vf[i], acc[i]);
         }
         m = mx;
+    };
+    if constexpr (PIPE) {
+        const int stride = NSTR * U;
+        const int n_it = (s_end - s_begin + stride - 1) / stride;   // block-uniform; a stream's own keys end up to one iteration earlier
+        int sA = s_first, sB = s_first + NSTR * UH;
+        // every load of the prologue (query, LayerNorm operands) has landed before the loop: the waitcnt pass merges the loop-entry
+        // state into every iteration, so a register still pending at entry costs a near-full drain per iteration (seen in the ISA
+        // as vmcnt(1) / vmcnt(0) in front of the first FMA that reads q).  vmcnt(0), lgkmcnt / expcnt untouched:
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (int it = 0; it < n_it; ++it) {
+            // (scheduling fences: without them the consumer of half B is hoisted above the requests of half A.  No branch in the loop
+            //  body: requests are unconditional and clamped -- the last iteration re-reads this block's last key -- so that the
+            //  waits stay counted, vmcnt(2 * UH), instead of vmcnt(0))
+            consume(0, sA);
+            sA += stride;
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(0, sA);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(1, sB);
+            sB += stride;
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(1, sB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int s0 = s_first; s0 < s_end; s0 += NSTR * U) {  // (a register double buffer of WHOLE tiles measured 0.5-1 us SLOWER per launch)
+            if (s0 != s_first) load_tile(kk, vv, s0);
+            consume(0, s0);
+        }
     }
 #pragma unroll
     for (int i = 0; i < DPL; i += 4) *reinterpret_cast<float4*>(&sm_o[sid][DPL * c + i]) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
@@ -827,11 +882,17 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     const bool nt = variant == 2 ? p.nt != 0 : variant != 0;
     // non-temporal K/V loads: 18.6 vs 20.4 us per medium.en cross-attention launch; default policy only when a whole decode
     // step fits the Infinity Cache (engine.hip: wt_decoder_begin)
+    // half-tile software pipeline (PIPE): measured per cross-attention launch, fp16 caches: batch 16 19.04 -> 18.69 us, batch 8
+    // 13.35 -> 12.84 (two splits) / 15.28 -> 13.49 (one); fp32 caches 19.87 vs 19.98 (no gain: a tenth of an iteration is arithmetic
+    // there, a fifth with fp16 caches) -- so fp16 caches only.  A/B: WT_ATTN_PIPE=0|1 forces it off / on for both.
+    static const int pipe = tuning_env("WT_ATTN_PIPE") ? atoi(tuning_env("WT_ATTN_PIPE")) : -1;
     if (p.kv_half) {
-        if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, true>), grid, dim3(256), 0, s, p);
+        if (nt && pipe != 0) hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true>), grid, dim3(256), 0, s, p);
+        else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((dec_attn_kernel<4, false, true>), grid, dim3(256), 0, s, p);
     } else {
-        if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false>), grid, dim3(256), 0, s, p);
+        if (nt && pipe == 1) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, true>), grid, dim3(256), 0, s, p);
+        else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((dec_attn_kernel<4, false, false>), grid, dim3(256), 0, s, p);
     }
     return hipGetLastError();

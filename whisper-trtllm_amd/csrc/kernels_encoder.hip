@@ -107,7 +107,8 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, floa
 
 // Epilogue shared by the two fp32 GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+template <int TJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][TJ], const int m0, const int n0, const int wr,
                                               const int wc, const int l31, const int hh) {
     // Row-dependent addressing (batch split, output row pointer) is computed once per row -- the batch index of the
     // wave's first row by ONE wave-uniform division, the rest by carry -- and the residual / position rows of a group of
@@ -118,8 +119,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     bool nok[2];
     int kv_which[2] = {0, 0}, kv_h[2] = {0, 0}, kv_j[2] = {0, 0};
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+    for (int tj = 0; tj < TJ; ++tj) {
+        nn[tj] = n0 + wc * (32 * TJ) + tj * 32 + l31;
         nok[tj] = nn[tj] < p.N;
         bv[tj] = (p.bias && nok[tj]) ? p.bias[nn[tj]] : 0.f;
         if (p.epi == EPI_KV_HEADS) {
@@ -153,18 +154,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
+                for (int tj = 0; tj < TJ; ++tj)
                     extra[ri][tj] = (p.resid && mok[ri] && nok[tj]) ? p.resid[offs[ri] + nn[tj]] : 0.f;
             float posv[4][2];
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
+                for (int tj = 0; tj < TJ; ++tj)
                     posv[ri][tj] = (p.pos && mok[ri] && nok[tj]) ? p.pos[(long long)crs[ri] * p.N + nn[tj]] : 0.f;
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj) {
+                for (int tj = 0; tj < TJ; ++tj) {
                     if (!(mok[ri] && nok[tj])) continue;
                     float v = acc[ti][tj][rq * 4 + ri] + bv[tj];
                     if (p.act) v = gelu_erf(v);
@@ -185,8 +186,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
 // loads -- never for the stores.  (gfx9 has ONE counter for loads and stores: in the generic epilogue above every `p.resid ? load : 0`
 // becomes a branch whose join waits vmcnt(0), i.e. for the round trip of all stores issued so far; measured per workgroup, its stores
 // took 13 us to ISSUE alone on a CU and 60 us beside other workgroups' K loops -- a third of a K = 1024 tile's life.)
-template <bool RESID, bool ACT, bool POS, bool KV>
-__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+template <bool RESID, bool ACT, bool POS, bool KV, int TJ>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[2][TJ], const int m0, const int n0, const int wr,
                                                    const int wc, const int l31, const int hh) {
     const int mw = m0 + wr * 64, rpb = p.c_rows_per_batch;
     const int cb_w = mw / rpb, cr_w = mw - cb_w * rpb;                 // wave-uniform: one division
@@ -194,8 +195,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
     float bv[2];
     float* base[2];
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        nn[tj] = n0 + wc * 64 + tj * 32 + l31;
+    for (int tj = 0; tj < TJ; ++tj) {
+        nn[tj] = n0 + wc * (32 * TJ) + tj * 32 + l31;
         bv[tj] = p.bias ? p.bias[nn[tj]] : 0.f;
         if (KV) {
             const int dkv = p.kv_heads * HEAD_DIM, which = nn[tj] / dkv, r2 = nn[tj] - which * dkv, h = r2 / HEAD_DIM;
@@ -224,7 +225,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
             int cr;
             const int off = row_of(g, ri, cr);
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
+            for (int tj = 0; tj < TJ; ++tj) {
                 if (RESID) rv[g & 1][ri * 2 + tj] = p.resid[off + col[tj]];
                 if (POS) pv[g & 1][ri * 2 + tj] = p.pos[cr * p.N + nn[tj]];
             }
@@ -237,7 +238,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
+            for (int tj = 0; tj < TJ; ++tj) {
                 float x = acc[g >> 2][tj][(g & 3) * 4 + ri] + bv[tj];
                 if (ACT) x = gelu_erf(x);
                 if (POS) x += pv[g & 1][ri * 2 + tj];
@@ -249,26 +250,27 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
             int cr;
             const int off = row_of(g, ri, cr);
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) base[tj][off + col[tj]] = v[ri * 2 + tj];
+            for (int tj = 0; tj < TJ; ++tj) base[tj][off + col[tj]] = v[ri * 2 + tj];
         }
         if ((RESID || POS) && g + 2 < 8) fetch(g + 2);
     }
 }
 
 // Epilogue dispatch: the fast form for interior sub-tiles of the operand combinations the engines use, the generic one otherwise.
-__device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[2][2], const int m0, const int n0, const int wr,
+template <int TJ>
+__device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[2][TJ], const int m0, const int n0, const int wr,
                                                   const int wc, const int l31, const int hh) {
-    const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * 64 + 64 <= p.N && p.c_rows_per_batch >= 64 && p.epi_fits32;
+    const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * (32 * TJ) + 32 * TJ <= p.N && p.c_rows_per_batch >= 64 && p.epi_fits32;
     if (interior && p.epi == EPI_ROWMAJOR && !p.pos) {
-        if (p.resid && !p.act) return gemm_epilogue_fast<true, false, false, false>(p, acc, m0, n0, wr, wc, l31, hh);
-        if (!p.resid && p.act) return gemm_epilogue_fast<false, true, false, false>(p, acc, m0, n0, wr, wc, l31, hh);
-        if (!p.resid && !p.act) return gemm_epilogue_fast<false, false, false, false>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (p.resid && !p.act) return gemm_epilogue_fast<true, false, false, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (!p.resid && p.act) return gemm_epilogue_fast<false, true, false, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (!p.resid && !p.act) return gemm_epilogue_fast<false, false, false, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
     } else if (interior && p.epi == EPI_ROWMAJOR && p.pos && p.act && !p.resid) {
-        return gemm_epilogue_fast<false, true, true, false>(p, acc, m0, n0, wr, wc, l31, hh);
+        return gemm_epilogue_fast<false, true, true, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
     } else if (interior && p.epi == EPI_KV_HEADS && !p.pos && !p.act && !p.resid) {
-        return gemm_epilogue_fast<false, false, false, true>(p, acc, m0, n0, wr, wc, l31, hh);
+        return gemm_epilogue_fast<false, false, false, true, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
     }
-    gemm_epilogue(p, acc, m0, n0, wr, wc, l31, hh);
+    gemm_epilogue<TJ>(p, acc, m0, n0, wr, wc, l31, hh);
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
         __syncthreads();
     }
 
-    gemm_epilogue_any(p, acc, m0, n0, wr, wc, l31, hh);
+    gemm_epilogue_any<2>(p, acc, m0, n0, wr, wc, l31, hh);
 }
 
 // The same GEMM with the tiles staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPR staging, no ds_write),
@@ -387,10 +389,14 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
 // SIMD sustain LESS MFMA throughput than three, tools/probes/mfma_rate.hip: 125 vs 155 TFLOP/s of pure v_mfma_f32_32x32x2_f32):
 // the DMA of tile kt+2 is issued right after the barrier that opens tile kt, and the wait at the top of a step is counted
 // (vmcnt(4): tile kt+1's four DMA instructions may still be in flight).
-template <bool STAMP>
+// BN = 64: a 128x64 block tile (wave tile 64x32, W stage half used) for launches whose 128x128 tiling fills the chip's 768 workgroup
+// slots badly (small.en's N = 768: 564 tiles) -- half-size tiles fill the last round better; same stages, same LDS footprint
+// (three workgroups per CU either way).
+template <bool STAMP, int BN>
 __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p) {
     constexpr int STAGES = 3;
     constexpr int BK = 16;
+    constexpr int TJ = BN / 64;            // 32-column MFMA tiles per wave
     long long t_start = 0, t_first = 0, t_loop = 0;   // probe build: wall-clock stamps (100 MHz)
     if (STAMP) t_start = wall_clock64();
     __shared__ __attribute__((aligned(1024))) float smem[STAGES][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
     const int wr = wave >> 1, wc = wave & 1;
 
     // XCD-aware tile order (see gemm_f32_kernel)
-    const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + GBM - 1) / GBM, total = nbx * nby;
     int bid = blockIdx.x;
     {
         const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
     const int per_group = GROUP_M * nbx, g = bid / per_group;
     const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
     const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
-    const int m0 = by * GBM, n0 = bx * GBN;
+    const int m0 = by * GBM, n0 = bx * BN;
 
     // DMA map: wave w, pass j fills rows j*64 + w*16 .. +15; lane -> (row lane >> 2, chunk position lane & 3)
     const int r_local = lane >> 2, csrc = (lane & 3) ^ ((r_local >> 2) & 3);
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
         const int m = min(m0 + row, p.M - 1);
         const int bb = m / p.a_rows_per_batch;
         aptr[j] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 4;
-        const int n = min(n0 + row, p.N - 1);
+        const int n = min(n0 + row, p.N - 1);   // (BN = 64: only j = 0 is used)
         wptr[j] = p.W + (long long)n * p.K + csrc * 4;
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -430,20 +436,20 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 64 + wave * 16) * BK]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+            if (j < TJ) __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 64 + wave * 16) * BK]), 16, 0, 0);
         }
     };
 
     // fragment reads: rows wr*64 + l31 (+32) of A, wc*64 + l31 (+32) of W; chunk 2q + hh at position (2q + hh) ^ swz
     const int swz = (l31 >> 2) & 3;
-    const int ra = (wr * 64 + l31) * BK, rb = (wc * 64 + l31) * BK;
+    const int ra = (wr * 64 + l31) * BK, rb = (wc * (32 * TJ) + l31) * BK;
     const int po0 = ((0 + hh) ^ swz) * 4, po1 = ((2 + hh) ^ swz) * 4;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < TJ; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
@@ -453,7 +459,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's share of tile kt has landed (with three stages tile kt+1's four DMA instructions may still be in flight)
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (kt + 1 < nk) {
+            if (TJ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... everyone's has, and nobody still reads the stage refilled next (the fragment reads of step kt-1 were waited for
         // before its MFMAs).  A raw s_barrier: __syncthreads() would add a vmcnt(0) fence and undo the counted wait.
@@ -472,20 +481,21 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ra + po);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
+            f32x4 b1 = b0;
+            if (TJ == 2) b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
             if (q == 0 && kt + STAGES - 1 < nk) dma(fill, kt + STAGES - 1);  // after the first fragment reads are on their way
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][1], 0, 0, 0);
+                if (TJ == 2) acc[0][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][TJ - 1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][1], 0, 0, 0);
+                if (TJ == 2) acc[1][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][TJ - 1], 0, 0, 0);
             }
         }
         cur = nxt;
     }
     if (STAMP) t_loop = wall_clock64();
-    gemm_epilogue_any(p, acc, m0, n0, wr, wc, l31, hh);
+    gemm_epilogue_any<TJ>(p, acc, m0, n0, wr, wc, l31, hh);
     if (STAMP) {
         const long long t_issued = wall_clock64();           // every store of this wave issued (the product kernel ends here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -534,8 +544,16 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
     static const bool no_dma = tuning_env("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
     if (!no_dma && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
     {
-        if (p.dbg_stamps) hipLaunchKernelGGL(gemm_f32_dma_kernel<true>, dim3(tiles), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(gemm_f32_dma_kernel<false>, dim3(tiles), dim3(256), 0, s, p);
+        // 128x64 tiles when they balance the CUs better.  Two or three co-resident workgroups saturate a CU's MFMA pipes alike, so
+        // a launch takes about ceil(tiles / 256 CUs) tile times; half-size tiles quantise that in half steps (5 % charged for their
+        // higher LDS traffic per flop): small.en's N = 768 launches, 564 tiles -> 3 tile times, 1128 half tiles -> 2.5.
+        static const int force_bn = tuning_env("WT_GEMM_BN") ? atoi(tuning_env("WT_GEMM_BN")) : 0;
+        const long long tiles64 = (long long)((p.N + 63) / 64) * nby;
+        const double cost128 = (double)((tiles + 255) / 256), cost64 = 0.5 * 1.05 * (double)((tiles64 + 255) / 256);
+        const bool bn64 = force_bn ? force_bn == 64 : cost64 < cost128;
+        if (p.dbg_stamps) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, 128>), dim3(tiles), dim3(256), 0, s, p);
+        else if (bn64) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 64>), dim3((unsigned)tiles64), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128>), dim3(tiles), dim3(256), 0, s, p);
     }
     else if (bk == 16) hipLaunchKernelGGL(gemm_f32_kernel<16>, dim3(tiles), dim3(256), gemm_smem_bytes<16>(), s, p);
     else hipLaunchKernelGGL(gemm_f32_kernel<32>, dim3(tiles), dim3(256), gemm_smem_bytes<32>(), s, p);
