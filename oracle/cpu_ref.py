@@ -63,47 +63,65 @@ def fp16_engine_weights(weights: Dict[str, np.ndarray], encoder: bool = False, d
 
 
 # ----------------------------------------------------------------------------- encoder
-def _encoder_attention(x: torch.Tensor, W: Weights, p: str, n_heads: int) -> torch.Tensor:
-    """HF/models/whisper/modeling_whisper.py:569-593 (WhisperEncoderAttention.forward)."""
+def _encoder_attention(x: torch.Tensor, W: Weights, p: str, n_heads: int, fp16_engine: bool = False) -> torch.Tensor:
+    """HF/models/whisper/modeling_whisper.py:569-593 (WhisperEncoderAttention.forward).
+
+    fp16_engine (this repo's fp16 encoder engine; x arrives fp16-rounded): q, k, v are stored as fp16, the scores and the softmax
+    are fp32 (TL model.py:292-295), the probabilities enter the P.V product as fp16 while their row sum stays fp32, and the context
+    is stored as fp16.  (The engine rounds exp(s - running max) tile by tile and rescales in fp32; rounding exp(s - max) once, as
+    here, has the same error size but not the same bits -- tests compare at a few 1e-4 of the range, not bit for bit.)"""
+    r = _r16 if fp16_engine else (lambda t: t)
     B, T, D = x.shape
     dh = D // n_heads
-    q = F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"]) * (dh ** -0.5)  # :572 q scaled BEFORE QK^T
-    k = F.linear(x, W[p + "k_proj.weight"])                                       # k_proj has no bias (:547)
-    v = F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"])
+    q = r(F.linear(x, W[p + "q_proj.weight"], W[p + "q_proj.bias"])) * (dh ** -0.5)  # :572 q scaled BEFORE QK^T (exact in fp16)
+    k = r(F.linear(x, W[p + "k_proj.weight"]))                                    # k_proj has no bias (:547)
+    v = r(F.linear(x, W[p + "v_proj.weight"], W[p + "v_proj.bias"]))
     sh = lambda t: t.view(B, T, n_heads, dh).transpose(1, 2)
     q, k, v = sh(q), sh(k), sh(v)
-    att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)                           # :581-583, no mask is ever added
-    ctx = (att @ v).transpose(1, 2).reshape(B, T, D)
+    if fp16_engine:
+        sc = q @ k.transpose(-1, -2)
+        e = torch.exp(sc - sc.max(dim=-1, keepdim=True).values)
+        ctx = r((_r16(e) @ v) / e.sum(dim=-1, keepdim=True))
+    else:
+        att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)                       # :581-583, no mask is ever added
+        ctx = att @ v
+    ctx = ctx.transpose(1, 2).reshape(B, T, D)
     return F.linear(ctx, W[p + "out_proj.weight"], W[p + "out_proj.bias"])
 
 
-def encoder_conv_frontend(W: Weights, cfg: dict, mel: torch.Tensor) -> torch.Tensor:
-    """HF modeling_whisper.py:992-997: conv1+GELU(erf), conv2(stride 2)+GELU, permute, + embed_positions."""
-    x = F.gelu(F.conv1d(mel, W["model.encoder.conv1.weight"], W["model.encoder.conv1.bias"], padding=1))
+def encoder_conv_frontend(W: Weights, cfg: dict, mel: torch.Tensor, fp16_engine: bool = False) -> torch.Tensor:
+    """HF modeling_whisper.py:992-997: conv1+GELU(erf), conv2(stride 2)+GELU, permute, + embed_positions.
+    fp16_engine: the mel and conv1's output are the fp16 A operands of the two implicit GEMMs."""
+    r = _r16 if fp16_engine else (lambda t: t)
+    x = r(F.gelu(F.conv1d(r(mel), W["model.encoder.conv1.weight"], W["model.encoder.conv1.bias"], padding=1)))
     x = F.gelu(F.conv1d(x, W["model.encoder.conv2.weight"], W["model.encoder.conv2.bias"], stride=2, padding=1))
     return x.permute(0, 2, 1) + W["model.encoder.embed_positions.weight"]
 
 
-def encoder_layer(W: Weights, cfg: dict, i: int, h: torch.Tensor) -> torch.Tensor:
-    """HF modeling_whisper.py:632-641 (pre-LN attention + pre-LN FFN)."""
+def encoder_layer(W: Weights, cfg: dict, i: int, h: torch.Tensor, fp16_engine: bool = False) -> torch.Tensor:
+    """HF modeling_whisper.py:632-641 (pre-LN attention + pre-LN FFN).  fp16_engine: LayerNorm outputs and the GELU output are the
+    fp16 A operands of the next GEMM; the residual stream stays fp32."""
+    r = _r16 if fp16_engine else (lambda t: t)
     p = f"model.encoder.layers.{i}."
     D = cfg["d_model"]
-    r = h
-    x = F.layer_norm(h, (D,), W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"], 1e-5)
-    h = r + _encoder_attention(x, W, p + "self_attn.", cfg["encoder_attention_heads"])
-    r = h
-    x = F.layer_norm(h, (D,), W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"], 1e-5)
-    x = F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"]))
-    return r + F.linear(x, W[p + "fc2.weight"], W[p + "fc2.bias"])
+    res = h
+    x = r(F.layer_norm(h, (D,), W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"], 1e-5))
+    h = res + _encoder_attention(x, W, p + "self_attn.", cfg["encoder_attention_heads"], fp16_engine)
+    res = h
+    x = r(F.layer_norm(h, (D,), W[p + "final_layer_norm.weight"], W[p + "final_layer_norm.bias"], 1e-5))
+    x = r(F.gelu(F.linear(x, W[p + "fc1.weight"], W[p + "fc1.bias"])))
+    return res + F.linear(x, W[p + "fc2.weight"], W[p + "fc2.bias"])
 
 
-def encoder_forward(W: Weights, cfg: dict, mel: torch.Tensor) -> torch.Tensor:
+def encoder_forward(W: Weights, cfg: dict, mel: torch.Tensor, fp16_engine: bool = False) -> torch.Tensor:
     """HF WhisperEncoder.forward modeling_whisper.py:992-1011 == TL model.py:90-111 (with erf GELU).
 
-    mel f32 [B, 80, 2*max_source_positions] -> f32 [B, max_source_positions, d_model]."""
-    h = encoder_conv_frontend(W, cfg, mel)
+    mel f32 [B, 80, 2*max_source_positions] -> f32 [B, max_source_positions, d_model].
+    fp16_engine: the arithmetic of this repo's fp16 encoder engine (pass `fp16_engine_weights(.., encoder=True)` as W): fp16 GEMM
+    operands, fp32 accumulation / residual stream / LayerNorm / softmax."""
+    h = encoder_conv_frontend(W, cfg, mel, fp16_engine)
     for i in range(cfg["encoder_layers"]):
-        h = encoder_layer(W, cfg, i, h)
+        h = encoder_layer(W, cfg, i, h, fp16_engine)
     D = cfg["d_model"]
     return F.layer_norm(h, (D,), W["model.encoder.layer_norm.weight"], W["model.encoder.layer_norm.bias"], 1e-5)
 

@@ -63,9 +63,12 @@ def test_greedy_ids_and_logits_match_golden(wt, case):
 
 @pytest.mark.parametrize("case", ["toy-short_b3", "toy-wide_b2", "tiny_b2"])
 def test_fp16_encoder_engine(wt, case):
-    """--engine_precision float16 (fp16 GEMM operands, fp32 accumulate/residual/LN/softmax) against the fp32 oracle.
-    The reference publishes no fp16 result for this path (README.md:82-88 has only fp32+fp32), so this is a
-    tolerance check, not a pinned parity: relative error of the encoder memory < 1e-2 of its dynamic range."""
+    """--engine_precision float16 (fp16 GEMM operands, fp32 accumulate/residual/LN/softmax).  The reference publishes no fp16
+    result for this path (README.md:82-88 has only fp32+fp32): the fp16 NUMBERS are parity-unpinned.  The ARITHMETIC is pinned:
+    the oracle's fp16_engine mode evaluates the fp32 model on fp16-rounded weights with activations rounded to fp16 exactly where
+    the engine stores them as GEMM operands, and the engine matches it to 1e-3 of the dynamic range (measured 1-3e-4: what is left
+    is elements that round the other way at a 1e-6 difference in the fp32 sums) -- against 1e-2 for the old fp32-oracle check."""
+    import cpu_ref
     z, cfg, weights, mel = load_case(case)
     blob = wt.convert.build_encoder_engine(cfg, weights, precision="float16")
     info, tensors = wt.engine_pack.unpack(blob)
@@ -77,9 +80,14 @@ def test_fp16_encoder_engine(wt, case):
     h16, h32 = enc16(x), enc32(x)
     torch.cuda.synchronize()
     assert h16.dtype == torch.float32 and torch.isfinite(h16).all()
-    err = (h16 - h32).abs().max().item()
     scale = h32.abs().max().item()
-    assert err < 1e-2 * scale, (err, scale)
+    W16 = cpu_ref.to_torch(cpu_ref.fp16_engine_weights(weights, encoder=True))
+    with torch.no_grad():
+        ref16 = cpu_ref.encoder_forward(W16, cfg, torch.from_numpy(mel), fp16_engine=True)
+    err16 = (h16.cpu() - ref16).abs().max().item()
+    print(f"{case}: fp16 encoder vs fp16 oracle {err16 / scale:.2e} of range, vs fp32 engine {(h16 - h32).abs().max().item() / scale:.2e}")
+    assert err16 < 1e-3 * scale, (err16, scale)
+    assert (h16 - h32).abs().max().item() < 1e-2 * scale          # and fp16 stays a small perturbation of the fp32 model
     np.testing.assert_allclose(sub(h16.cpu().numpy()), z["enc_out"], atol=1e-2 * scale)
     # fp16 encoder + fp32 decoder decodes (config 4 plumbing); ids need not equal the fp32 path at near-ties
     dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
