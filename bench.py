@@ -265,7 +265,7 @@ def main():
         attn_flop = B * cfg["encoder_layers"] * 4 * H * S * S * 64
         half = args.encoder_precision == "float16"
         enc_peak = 2500.0 if half else MFMA_F32_PEAK_TF
-        out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
+        out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma4_kernel / gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
                                    "achieved": round(gemm_tf, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(gemm_tf / enc_peak, 4),
                                    "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
                                    "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,

@@ -116,16 +116,18 @@ def test_gemm_f16(lib, M, N, K, act, out_half, use_res):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 4])
 @pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
     (130, 70, 64, 0, 0, False), (257, 129, 128, 1, 1, False), (1500, 1024, 4096, 0, 0, True), (3000, 1024, 3072, 1, 0, False),
     (1024, 3072, 1024, 0, 1, False), (300, 200, 192, 0, 0, True), (256, 128, 64, 0, 0, False), (511, 383, 640, 1, 1, False),
     # more than 256 tiles of 256x128: the persistent kernel's workgroups walk 2+ tiles each (tile switch inside the K-step stream,
     # epilogue under the next tile's DMA), with 1, 2 and 3 K-steps per tile (pipeline shorter than / equal to its depth) and ragged edges
-    (8192, 1152, 64, 0, 0, False), (8192, 1152, 128, 1, 1, False), (20000, 520, 192, 0, 0, True), (9000, 1030, 256, 0, 1, False)])
+    (8192, 1152, 64, 0, 0, False), (8192, 1152, 128, 1, 1, False), (20000, 520, 192, 0, 0, True), (9000, 1030, 256, 0, 1, False),
+    # more than 256 tiles of 256x256 as well (the 256x256x32 four-stage kernel: 2, 4, 6 K-steps of 32 per tile)
+    (8192, 2304, 64, 1, 1, False), (20000, 1030, 128, 0, 0, True), (12000, 1540, 192, 0, 1, False)])
 def test_gemm_f16_lds_dma_kernels(lib, variant, M, N, K, act, out_half, use_res):
-    """Both LDS-DMA fp16 GEMM kernels (128x128 two-stage; 256x128 three-stage with counted vmcnt + raw barrier) forced at sizes the
-    shape rule would not give them: ragged M / N tiles, 1..64 K-tiles, every epilogue form."""
+    """The LDS-DMA fp16 GEMM kernels (128x128 two-stage; persistent 256x128x64 three-stage and 256x256x32 four-stage with counted
+    vmcnt + raw barrier) forced at sizes the shape rule would not give them: ragged M / N tiles, 1..64 K-tiles, every epilogue form."""
     A, W, b = _rand(M, K, seed=1).half(), _rand(N, K, seed=2, scale=K ** -0.5).half(), _rand(N, seed=3)
     R = _rand(M, N, seed=4) if use_res else None
     ref = F.linear(A.double(), W.double(), b.double())

@@ -184,6 +184,35 @@ def _bench_gemm_f16(M):
             print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh} +resid: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_gemm_f16_variants():
+    """fp16 GEMM kernels side by side on the encoder's shapes: 2 = 128x128x64 two-stage, 3 = persistent 256x128x64, 4 = persistent
+    256x256x32 (round 3); 0 = what the shape rule picks"""
+    for M in (12000, 24000):
+        for (N, K, act, oh) in ((3072, 1024, 0, 1), (4096, 1024, 1, 1), (1024, 4096, 0, 0), (1024, 1024, 0, 0), (2048, 1024, 0, 1)):
+            A = torch.randn(M, K, device="cuda").half()
+            W = (torch.randn(4, N, K, device="cuda") * 0.03).half()
+            bias = torch.zeros(N, device="cuda")
+            C = torch.empty(M, N, device="cuda", dtype=torch.float16 if oh else torch.float32)
+            row = []
+            for variant in (0, 2, 3, 4):
+                fn = (lambda i: lib.wt_dbg_gemm_f16(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, ST())) if variant == 0 else \
+                     (lambda i: lib.wt_dbg_gemm_f16_variant(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, variant, ST()))
+                us = timeit(fn, 4, iters=5)
+                row.append(f"v{variant} {us:7.1f} us {2.0 * M * N * K / us * 1e-6:6.0f} TF")
+            print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh}: " + " | ".join(row))
+
+
+def bench_gemm_f16_v4(M=24000):
+    """the 256x256x32 kernel alone on its two shapes (for the WT_HGEMM_ABLATE probe: 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads)"""
+    for (N, K, act, oh) in ((3072, 1024, 0, 1), (4096, 1024, 0, 1), (3072, 4096, 0, 1)):
+        A = torch.randn(M, K, device="cuda").half()
+        W = (torch.randn(4, N, K, device="cuda") * 0.03).half()
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda", dtype=torch.float16)
+        us = timeit(lambda i: lib.wt_dbg_gemm_f16_variant(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, 4, ST()), 4, iters=5)
+        print(f"v4 M={M} N={N} K={K}: {us:7.1f} us  ({2.0 * M * N * K / us * 1e-6:6.0f} TF if it were the full product)")
+
+
 def bench_gemm_f16_resident(M=24000, N=1024):
     """Is the fp16 GEMM's K loop bound by the latency of its compulsory L2 misses?  Same launches with lda = 0: every row of A is the
     same 2*K bytes, so A is L1/L2-resident and only W (2-8 MB) streams -- if the loop speeds up a lot, it was waiting for misses."""

@@ -783,6 +783,171 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
     }
 }
 
+// PERSISTENT 256x256x32 kernel (round 3): 8 waves as 2 x 4, 128 x 64 per wave, FOUR 32 KiB stages + 16 KiB of epilogue scratch.
+// Why this shape: per K-step of 64 the 256x128 kernel above moves 48 KiB INTO a CU's LDS and reads 128 KiB of fragments out of it for
+// 0.43 us of MFMA time -- the LDS pipe (about 250 B/clk for b128 reads, far less for writes: MI355X_MICROARCH.md) is the busier unit.
+// A 256x256 block writes a third fewer operand bytes per flop, and a 128x64 wave tile reads a quarter fewer.  Everything else is the
+// scheme of gemm_f16_dma3_kernel: one workgroup per CU streaming the K-steps of all its tiles, LDS-DMA into unpadded XOR-swizzled
+// stages (64-byte rows: position p of row r holds chunk p ^ ((r >> 2) & 3), every 16-lane ds_read_b128 group covers the 16 slots of
+// a 256-byte bank row), counted vmcnt waits + raw s_barrier, fragments double-buffered in registers.  One K-step = 32 deep:
+//   reads A_hi(g) | MFMA A_lo(g) x B(g) | wait step g+1 + barrier | DMA(step g+4 -> stage g%4) | reads A_lo(g+1), B(g+1) | MFMA A_hi(g) x B(g)
+constexpr int H4_BM = 256, H4_BN = 256, H4_BK = 32, H4_NST = 4, H4_STAGE = (H4_BM + H4_BN) * H4_BK;   // halfs per stage (32 KiB)
+constexpr int H4_SMEM = H4_NST * H4_STAGE * 2 + H3_SCRATCH;                                             // 147,456 B
+template <bool OUT_HALF>
+__global__ __launch_bounds__(512, 2) void gemm_f16_dma4_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char h4_raw[];
+    _Float16* smem = reinterpret_cast<_Float16*>(h4_raw);   // [stage][A 256 rows | W 256 rows][row * 32 + pos * 8], then the scratch
+    const __half* A = reinterpret_cast<const __half*>(p.A);
+    const __half* W = reinterpret_cast<const __half*>(p.W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;                 // 2 x 4 waves, 128 x 64 each
+    float* ew = reinterpret_cast<float*>(h4_raw + H4_NST * H4_STAGE * 2) + wave * (8 * 64);
+
+    const int nbx = (p.N + H4_BN - 1) / H4_BN, nby = (p.M + H4_BM - 1) / H4_BM, total = nbx * nby;
+    const int G = gridDim.x;
+    const int ntiles = ((int)blockIdx.x < total) ? (total - (int)blockIdx.x + G - 1) / G : 0;
+    if (ntiles == 0) return;                                   // block-uniform
+    auto tile_origin = [&](const int i, int& m0, int& n0) {    // i-th tile of this workgroup (XCD-chunked, GROUP_M row tiles per column sweep)
+        int bid = (int)blockIdx.x + i * G;
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * nbx, g = bid / per_group;
+        const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+        m0 = (g * GROUP_M + in_g % gm) * H4_BM;
+        n0 = (in_g / gm) * H4_BN;
+    };
+    // DMA map: one wave instruction = 16 rows x 64 B.  A and W: 16 instructions each per K-step (wave w, pass j < 2: rows j*128 + w*16 ..).
+    const int r_local = lane >> 2;
+    const int csrc = (lane & 3) ^ ((r_local >> 2) & 3);
+    // per-lane BYTE offsets of the four source rows (32 bits: launch_gemm_f16 checks the operands span < 4 GiB); the K-step's column
+    // offset is wave-uniform and goes into the scalar base, so a request is `global_load_lds v_off, s[base]` and the running pointers
+    // cost four VGPRs, not sixteen (the kernel is at the 256-register limit of two waves per SIMD)
+    unsigned aoff[2], woff[2];
+    auto set_tile_ptrs = [&](const int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = min(m0 + j * 128 + wave * 16 + r_local, p.M - 1);
+            const int bb = m / p.a_rows_per_batch;
+            aoff[j] = (unsigned)(((long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8) * 2);
+            woff[j] = (unsigned)(((long long)min(n0 + j * 128 + wave * 16 + r_local, p.N - 1) * p.K + csrc * 8) * 2);
+        }
+    };
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const int stage, const int kt) {
+        _Float16* st = smem + stage * H4_STAGE;
+        const char* ab = reinterpret_cast<const char*>(A) + (long long)kt * (H4_BK * 2);   // wave-uniform
+        const char* wb = reinterpret_cast<const char*>(W) + (long long)kt * (H4_BK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + aoff[j]), (lptr_t)(st + (j * 128 + wave * 16) * H4_BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wb + woff[j]), (lptr_t)(st + H4_BM * H4_BK + (j * 128 + wave * 16) * H4_BK), 16, 0, 0);
+        }
+    };
+    const int po = ((kq ^ ((l15 >> 2) & 3)) * 8);
+    const int ra = (wr * 128 + l15) * H4_BK + po, rb = H4_BM * H4_BK + (wc * 64 + l15) * H4_BK + po;
+
+    f32x4 acc_lo[4][4], acc_hi[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_lo[i][j] = acc_hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / H4_BK;
+    const int steps = ntiles * nk;
+    int d_i = 0, d_kt = 0;
+    set_tile_ptrs(0);
+    auto dma_next = [&](const int stage) {
+        dma(stage, d_kt);
+        if (++d_kt == nk) {
+            d_kt = 0;
+            if (++d_i < ntiles) set_tile_ptrs(d_i);
+        }
+    };
+    dma_next(0);
+    if (steps > 1) dma_next(1);
+    if (steps > 2) dma_next(2);
+    if (steps > 3) dma_next(3);
+    if (steps > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (steps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (steps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    h8 fa0[4], fa1[4], fb[4];   // A fragments double-buffered (rows 0..63 / 64..127 of the wave tile), B single: 256 VGPRs are the limit
+    auto frag_a = [&](h8 (&fa)[4], const int stage, const int half) {   // half 0: rows 0..63 of the wave tile, 1: rows 64..127
+        const _Float16* st = smem + stage * H4_STAGE + ra + half * 64 * H4_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const h8*>(st + i * 16 * H4_BK);
+    };
+    auto frag_b2 = [&](const int stage, const int j0) {   // B fragments j0, j0 + 1 (columns 16 j0 .. 16 j0 + 31 of the wave tile)
+        const _Float16* st = smem + stage * H4_STAGE + rb;
+        fb[j0] = *reinterpret_cast<const h8*>(st + j0 * 16 * H4_BK);
+        fb[j0 + 1] = *reinterpret_cast<const h8*>(st + (j0 + 1) * 16 * H4_BK);
+    };
+    auto mma_cols = [&](f32x4 (&acc)[4][4], const h8 (&fa)[4], const int j0) {   // 8 MFMAs: all four row tiles x column tiles j0, j0 + 1
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    frag_a(fa0, 0, 0);
+    frag_b2(0, 0);
+    frag_b2(0, 2);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): both edges into the loop header carry an empty LDS scoreboard
+    int cur = 0, kt = 0, c_i = 0, m0, n0, skip = 0;
+    tile_origin(0, m0, n0);
+    for (int g = 0; g < steps; ++g) {
+        const int nxt = (cur + 1) & 3;
+        const bool more = g + 1 < steps;
+        frag_a(fa1, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_cols(acc_lo, fa0, 0);
+        mma_cols(acc_lo, fa0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my reads of stage `cur` are done (16 MFMAs were queued behind them)
+        if (more) {
+            if (skip) skip = 0;                                                      // waited for before the last epilogue's stores
+            else if (g + 3 < steps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // step g+1 landed (steps g+2, g+3 may fly)
+            else if (g + 2 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (g + 4 < steps) dma_next(cur);
+            frag_a(fa0, nxt, 0);
+        }
+        // the B fragments of step g+1 replace this step's pair by pair, each pair right behind the eight MFMAs that read it last
+        __builtin_amdgcn_sched_barrier(0);
+        mma_cols(acc_hi, fa1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) frag_b2(nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_cols(acc_hi, fa1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) frag_b2(nxt, 2);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) alone (see gemm_f16_dma3_kernel)
+        cur = nxt;
+        if (++kt == nk) {   // this tile's K is complete: finish it under the flight of the next tile's first K-steps
+            if (g + 4 < steps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // step g+2 landed; steps g+3, g+4 may fly
+            else if (g + 3 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            skip = 1;
+            hgemm_epilogue_lds8_any<OUT_HALF>(p, acc_lo, m0, n0, 2 * wr, wc, lane, ew);
+            hgemm_epilogue_lds8_any<OUT_HALF>(p, acc_hi, m0, n0, 2 * wr + 1, wc, lane, ew);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc_lo[i][j] = acc_hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            if (++c_i < ntiles) tile_origin(c_i, m0, n0);
+        }
+    }
+}
+
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7)) return hipErrorInvalidValue;
@@ -806,15 +971,38 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;
     const dim3 grid(nbx * nby);
     static const bool no_dma = tuning_env("WT_HGEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
-    // A/B override: WT_HGEMM_VARIANT=2 forces the 128x128 two-stage kernel, 3 the 256x128 three-stage kernel wherever M >= 1024.
-    // Default (measured, TFLOP/s, 128x128 two-stage vs 256x128 three-stage software-pipelined; N / K / epilogue):
-    //   M = 12000: 3072/1024 688 vs 655, 1024/1024 588 vs 512, 4096/1024 GELU fp16-out 604 vs 593, 1024/4096 805 vs 756, 1024/3072 732 vs 668
-    //   M = 24000: 3072/1024 687 vs 712, 1024/1024 678 vs 682, 4096/1024 GELU fp16-out 622 vs 610, 1024/4096 823 vs 904, 1024/3072 773 vs 840
-    // -> the big tile pays once there are >= ~3 rounds of 256x128 tiles per CU (batch 16); the 128x128 tiles fill the chip better below.
+    // A/B override: WT_HGEMM_VARIANT=2 forces the 128x128 two-stage kernel, 3 the persistent 256x128x64 kernel, 4 the persistent
+    // 256x256x32 kernel (wherever their shape limits allow).
+    // Default (measured in round 3, one box, TFLOP/s: 128x128 | 256x128 | 256x256; N / K / epilogue):
+    //   M = 12000: 3072/1024 fp16-out 680 | 769 | 726;  4096/1024 GELU fp16-out 597 | 654 | 688;  2048/1024 fp16-out 716 | 834 | 717;
+    //              1024/4096 804 | 787 | 823;  1024/1024 584 | 614 | 604
+    //   M = 24000: 3072/1024 fp16-out 722 | 832 | 867;  4096/1024 GELU fp16-out 626 | 667 | 703;  2048/1024 fp16-out 741 | 866 | 905;
+    //              1024/4096 823 | 938 | 764;  1024/1024 648 | 761 | 663
+    // -> 256x256 for the wide fp16-output GEMMs (q|k|v, fc1) once its tiles fill the chip several times over; 256x128 for the other
+    //    large launches (N = 1024 keeps the fp32 residual stream and has 4 column tiles of 256: 1.5 rounds of the chip); 128x128 below.
     static const int env_variant = tuning_env("WT_HGEMM_VARIANT") ? atoi(tuning_env("WT_HGEMM_VARIANT")) : 0;
-    const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach both kernels at small sizes
+    const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach every kernel at small sizes
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
-    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 ? false : p.M >= 16384;
+    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 || variant == 4 ? false : (p.M >= 16384 || (p.M >= 8192 && p.N >= 2048));
+    const bool span32 = (long long)((p.M + p.a_rows_per_batch - 1) / p.a_rows_per_batch) * (p.a_batch_stride > 0 ? p.a_batch_stride : 0) * 2 +
+                                (long long)p.a_rows_per_batch * p.lda * 2 < (1ll << 32) && (long long)p.N * p.K * 2 < (1ll << 32);
+    const long long tiles256 = (long long)((p.N + H4_BN - 1) / H4_BN) * ((p.M + H4_BM - 1) / H4_BM);
+    const bool use4 = !kv && (p.K % H4_BK) == 0 && span32 &&
+                      (variant == 4 || (variant == 0 && out_half && ((p.M >= 16384 && p.N >= 2048) || (p.M >= 8192 && p.N >= 4096)) && tiles256 >= 700));
+    if (dma_ok && use4) {
+        static PerDeviceFlag attr4;
+        if (!attr4.get()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H4_SMEM);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H4_SMEM);
+            if (e != hipSuccess) return e;
+            attr4.set();
+        }
+        const int tiles4 = ((p.N + H4_BN - 1) / H4_BN) * ((p.M + H4_BM - 1) / H4_BM);
+        const dim3 grid4(tiles4 < 256 ? tiles4 : 256);
+        if (out_half) hipLaunchKernelGGL(gemm_f16_dma4_kernel<true>, grid4, dim3(512), H4_SMEM, s, p);
+        else hipLaunchKernelGGL(gemm_f16_dma4_kernel<false>, grid4, dim3(512), H4_SMEM, s, p);
+        return hipGetLastError();
+    }
     if (dma_ok && use3) {
         static PerDeviceFlag attr3;
         if (!attr3.get()) {
