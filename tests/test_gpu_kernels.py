@@ -116,7 +116,7 @@ def test_gemm_f16(lib, M, N, K, act, out_half, use_res):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K,act,out_half,use_res", [
     (130, 70, 64, 0, 0, False), (257, 129, 128, 1, 1, False), (1500, 1024, 4096, 0, 0, True), (3000, 1024, 3072, 1, 0, False),
     (1024, 3072, 1024, 0, 1, False), (300, 200, 192, 0, 0, True), (256, 128, 64, 0, 0, False), (511, 383, 640, 1, 1, False),

@@ -194,7 +194,7 @@ def bench_gemm_f16_variants():
             bias = torch.zeros(N, device="cuda")
             C = torch.empty(M, N, device="cuda", dtype=torch.float16 if oh else torch.float32)
             row = []
-            for variant in (0, 2, 3, 4):
+            for variant in (0, 2, 3, 4, 5):
                 fn = (lambda i: lib.wt_dbg_gemm_f16(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, ST())) if variant == 0 else \
                      (lambda i: lib.wt_dbg_gemm_f16_variant(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, oh, variant, ST()))
                 us = timeit(fn, 4, iters=5)

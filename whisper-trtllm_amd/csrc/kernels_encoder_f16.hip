@@ -948,6 +948,173 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma4_kernel(const GemmParams 
     }
 }
 
+// The same 256x256x32 tiles and stages on the guide's TWO-GROUP schedule ("256^2 8-phase template", cdna_hip_programming.md): waves 0-3
+// (rows 0..127 of the block tile) and waves 4-7 (rows 128..255) -- one wave of each group per SIMD -- run the same sequence of blocks
+//   R1: read A_lo, B of step g | M1: 16 MFMAs | R2: read A_hi, wait for step g+1's LDS-DMA, request step g+3 | M2: 16 MFMAs
+// with a barrier after every block, group 1 ONE barrier behind group 0: in every interval one wave of a SIMD multiplies while the
+// other reads and requests.  (gemm_f16_dma4_kernel's ablation: the request -> land -> barrier chain and the read -> MFMA -> barrier
+// chain of a K-step are each ~1 us and ran back to back there, both waves of a SIMD wanting the MFMA pipe in the same window.)
+// Fragments need no double buffering: a block's reads are consumed right after the next barrier, under the OTHER group's MFMAs.
+// Ordering of the LDS-DMA: a wave waits (counted vmcnt) for its share of step g+1 in R2(g), before that block's barrier; the first
+// read of step g+1 is group 0's R1(g+1), two barriers after group 0's wait and one after group 1's.  The stage refilled in R2(g) is
+// (g+3) % 4 = (g-1) % 4, last read in group 1's R2(g-1), retired (lgkmcnt(0)) at the top of its M2(g-1) -- two barriers before group
+// 0's R2(g), three before group 1's.  Every wave executes 4 * steps + 1 barriers (group 1: one before its first block, group 0: one
+// after its last); nothing between two barriers depends on a wave-divergent condition.
+template <bool OUT_HALF>
+__global__ __launch_bounds__(512, 2) void gemm_f16_dma5_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char h4_raw[];
+    _Float16* smem = reinterpret_cast<_Float16*>(h4_raw);   // [stage][A 256 rows | W 256 rows][row * 32 + pos * 8], then the scratch
+    const __half* A = reinterpret_cast<const __half*>(p.A);
+    const __half* W = reinterpret_cast<const __half*>(p.W);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;                 // 2 x 4 waves, 128 x 64 each
+    float* ew = reinterpret_cast<float*>(h4_raw + H4_NST * H4_STAGE * 2) + wave * (8 * 64);
+
+    const int nbx = (p.N + H4_BN - 1) / H4_BN, nby = (p.M + H4_BM - 1) / H4_BM, total = nbx * nby;
+    const int G = gridDim.x;
+    const int ntiles = ((int)blockIdx.x < total) ? (total - (int)blockIdx.x + G - 1) / G : 0;
+    if (ntiles == 0) return;                                   // block-uniform
+    auto tile_origin = [&](const int i, int& m0, int& n0) {    // i-th tile of this workgroup (XCD-chunked, GROUP_M row tiles per column sweep)
+        int bid = (int)blockIdx.x + i * G;
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * nbx, g = bid / per_group;
+        const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+        m0 = (g * GROUP_M + in_g % gm) * H4_BM;
+        n0 = (in_g / gm) * H4_BN;
+    };
+    // DMA map: one wave instruction = 16 rows x 64 B.  A and W: 16 instructions each per K-step (wave w, pass j < 2: rows j*128 + w*16 ..).
+    const int r_local = lane >> 2;
+    const int csrc = (lane & 3) ^ ((r_local >> 2) & 3);
+    // per-lane BYTE offsets of the four source rows (32 bits: launch_gemm_f16 checks the operands span < 4 GiB); the K-step's column
+    // offset is wave-uniform and goes into the scalar base, so a request is `global_load_lds v_off, s[base]` and the running pointers
+    // cost four VGPRs, not sixteen (the kernel is at the 256-register limit of two waves per SIMD)
+    unsigned aoff[2], woff[2];
+    auto set_tile_ptrs = [&](const int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = min(m0 + j * 128 + wave * 16 + r_local, p.M - 1);
+            const int bb = m / p.a_rows_per_batch;
+            aoff[j] = (unsigned)(((long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8) * 2);
+            woff[j] = (unsigned)(((long long)min(n0 + j * 128 + wave * 16 + r_local, p.N - 1) * p.K + csrc * 8) * 2);
+        }
+    };
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](const int stage, const int kt) {
+        _Float16* st = smem + stage * H4_STAGE;
+        const char* ab = reinterpret_cast<const char*>(A) + (long long)kt * (H4_BK * 2);   // wave-uniform
+        const char* wb = reinterpret_cast<const char*>(W) + (long long)kt * (H4_BK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + aoff[j]), (lptr_t)(st + (j * 128 + wave * 16) * H4_BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wb + woff[j]), (lptr_t)(st + H4_BM * H4_BK + (j * 128 + wave * 16) * H4_BK), 16, 0, 0);
+        }
+    };
+    const int po = ((kq ^ ((l15 >> 2) & 3)) * 8);
+    const int ra = (wr * 128 + l15) * H4_BK + po, rb = H4_BM * H4_BK + (wc * 64 + l15) * H4_BK + po;
+
+    f32x4 acc_lo[4][4], acc_hi[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_lo[i][j] = acc_hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / H4_BK;
+    const int steps = ntiles * nk;
+    int d_i = 0, d_kt = 0;
+    set_tile_ptrs(0);
+    auto dma_next = [&](const int stage) {
+        dma(stage, d_kt);
+        if (++d_kt == nk) {
+            d_kt = 0;
+            if (++d_i < ntiles) set_tile_ptrs(d_i);
+        }
+    };
+    dma_next(0);
+    if (steps > 1) dma_next(1);
+    if (steps > 2) dma_next(2);
+    if (steps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (steps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // step 0 has landed for everybody
+    asm volatile("" ::: "memory");
+    if (wr == 1) {                         // group 1 runs one interval behind group 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    h8 fa[4], fb[4];
+    auto frag_a = [&](const int stage, const int half) {   // half 0: rows 0..63 of the wave tile, 1: rows 64..127
+        const _Float16* st = smem + stage * H4_STAGE + ra + half * 64 * H4_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const h8*>(st + i * 16 * H4_BK);
+    };
+    auto frag_b = [&](const int stage) {
+        const _Float16* st = smem + stage * H4_STAGE + rb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const h8*>(st + j * 16 * H4_BK);
+    };
+    auto mma = [&](f32x4 (&acc)[4][4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int cur = 0, kt = 0, c_i = 0, m0, n0, skip = 0;
+    tile_origin(0, m0, n0);
+    for (int g = 0; g < steps; ++g) {
+        // ---- R1: this step's first fragments (stage `cur` = step g landed and was published two barriers ago at the latest)
+        frag_b(cur);
+        frag_a(cur, 0);
+        bar();
+        // ---- M1
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        mma(acc_lo);
+        bar();
+        // ---- R2: second half of A; step g+1 must have landed before the barrier that ends this block; refill stage (g+3) % 4
+        frag_a(cur, 1);
+        if (g + 1 < steps) {
+            if (skip) skip = 0;                                                      // waited for before the last epilogue's stores
+            else if (g + 2 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // step g+1 landed (step g+2 may fly)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (g + 3 < steps) dma_next((cur + 3) & 3);
+        bar();
+        // ---- M2
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        mma(acc_hi);
+        bar();
+        cur = (cur + 1) & 3;
+        if (++kt == nk) {   // this tile's K is complete (no barrier in here: the other group runs on by at most one interval)
+            // the wait R2(g+1) would take -- step g+2 landed, step g+3 may fly -- is taken now, ahead of the epilogue's stores
+            if (g + 3 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            skip = 1;
+            hgemm_epilogue_lds8_any<OUT_HALF>(p, acc_lo, m0, n0, 2 * wr, wc, lane, ew);
+            hgemm_epilogue_lds8_any<OUT_HALF>(p, acc_hi, m0, n0, 2 * wr + 1, wc, lane, ew);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc_lo[i][j] = acc_hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            if (++c_i < ntiles) tile_origin(c_i, m0, n0);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0's last barrier pairs with group 1's last block
+}
+
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7)) return hipErrorInvalidValue;
@@ -983,12 +1150,28 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
     static const int env_variant = tuning_env("WT_HGEMM_VARIANT") ? atoi(tuning_env("WT_HGEMM_VARIANT")) : 0;
     const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach every kernel at small sizes
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
-    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 || variant == 4 ? false : (p.M >= 16384 || (p.M >= 8192 && p.N >= 2048));
+    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 || variant == 4 || variant == 5 ? false : (p.M >= 16384 || (p.M >= 8192 && p.N >= 2048));
+    const long long tiles256 = (long long)((p.N + H4_BN - 1) / H4_BN) * ((p.M + H4_BM - 1) / H4_BM);
     const bool span32 = (long long)((p.M + p.a_rows_per_batch - 1) / p.a_rows_per_batch) * (p.a_batch_stride > 0 ? p.a_batch_stride : 0) * 2 +
                                 (long long)p.a_rows_per_batch * p.lda * 2 < (1ll << 32) && (long long)p.N * p.K * 2 < (1ll << 32);
-    const long long tiles256 = (long long)((p.N + H4_BN - 1) / H4_BN) * ((p.M + H4_BM - 1) / H4_BM);
     const bool use4 = !kv && (p.K % H4_BK) == 0 && span32 &&
                       (variant == 4 || (variant == 0 && out_half && ((p.M >= 16384 && p.N >= 2048) || (p.M >= 8192 && p.N >= 4096)) && tiles256 >= 700));
+    // the two-group kernel: at its best on long K in ONE round of tiles (fc2 / conv2 of a batch-8 fp16 encoder: 188 tiles, K = 3072 / 4096:
+    // 1018 vs 825-890 TFLOP/s for the other kernels); with K = 1024 the per-tile epilogue and the fill of the last round decide, not the loop
+    const bool use5 = !kv && (p.K % H4_BK) == 0 && span32 && (variant == 5 || (variant == 0 && p.K >= 2048 && tiles256 <= 256 && tiles256 >= 160));
+    if (dma_ok && use5) {
+        static PerDeviceFlag attr5;
+        if (!attr5.get()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma5_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H4_SMEM);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma5_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H4_SMEM);
+            if (e != hipSuccess) return e;
+            attr5.set();
+        }
+        const dim3 grid5(tiles256 < 256 ? (unsigned)tiles256 : 256u);
+        if (out_half) hipLaunchKernelGGL(gemm_f16_dma5_kernel<true>, grid5, dim3(512), H4_SMEM, s, p);
+        else hipLaunchKernelGGL(gemm_f16_dma5_kernel<false>, grid5, dim3(512), H4_SMEM, s, p);
+        return hipGetLastError();
+    }
     if (dma_ok && use4) {
         static PerDeviceFlag attr4;
         if (!attr4.get()) {
