@@ -1150,7 +1150,7 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
     static const int env_variant = tuning_env("WT_HGEMM_VARIANT") ? atoi(tuning_env("WT_HGEMM_VARIANT")) : 0;
     const int variant = force_variant ? force_variant : env_variant;   // force_variant: kernel tests reach every kernel at small sizes
     const bool dma_ok = !no_dma && (p.K % 64) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
-    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 || variant == 4 || variant == 5 ? false : (p.M >= 16384 || (p.M >= 8192 && p.N >= 2048));
+    const bool use3 = kv ? false : variant == 3 ? (force_variant || p.M >= 1024) : variant == 2 || variant == 5 ? false : variant == 4 ? !out_half : (p.M >= 16384 || (p.M >= 8192 && p.N >= 2048));
     const long long tiles256 = (long long)((p.N + H4_BN - 1) / H4_BN) * ((p.M + H4_BM - 1) / H4_BM);
     const bool span32 = (long long)((p.M + p.a_rows_per_batch - 1) / p.a_rows_per_batch) * (p.a_batch_stride > 0 ? p.a_batch_stride : 0) * 2 +
                                 (long long)p.a_rows_per_batch * p.lda * 2 < (1ll << 32) && (long long)p.N * p.K * 2 < (1ll << 32);
@@ -1172,18 +1172,16 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
         else hipLaunchKernelGGL(gemm_f16_dma5_kernel<false>, grid5, dim3(512), H4_SMEM, s, p);
         return hipGetLastError();
     }
-    if (dma_ok && use4) {
+    if (dma_ok && use4 && out_half) {   // fp16-output form only: the fp32-output instantiation spills (36 bytes in its tile-switch path) and
+                                        // no shape rule selects it -- a forced variant 4 with fp32 output takes the 256x128 kernel below
         static PerDeviceFlag attr4;
         if (!attr4.get()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H4_SMEM);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H4_SMEM);
             if (e != hipSuccess) return e;
             attr4.set();
         }
-        const int tiles4 = ((p.N + H4_BN - 1) / H4_BN) * ((p.M + H4_BM - 1) / H4_BM);
-        const dim3 grid4(tiles4 < 256 ? tiles4 : 256);
-        if (out_half) hipLaunchKernelGGL(gemm_f16_dma4_kernel<true>, grid4, dim3(512), H4_SMEM, s, p);
-        else hipLaunchKernelGGL(gemm_f16_dma4_kernel<false>, grid4, dim3(512), H4_SMEM, s, p);
+        const dim3 grid4(tiles256 < 256 ? (unsigned)tiles256 : 256u);
+        hipLaunchKernelGGL(gemm_f16_dma4_kernel<true>, grid4, dim3(512), H4_SMEM, s, p);
         return hipGetLastError();
     }
     if (dma_ok && use3) {
