@@ -55,7 +55,9 @@ def test_gemm(lib, M, N, K, act, use_res):
     # more than one round of 128x128 tiles (> 768 workgroups) with 3 (= pipeline depth), 4 and 16 K-steps per tile and ragged last
     # tile row / column: interior sub-tiles take the branch-free epilogue, edge sub-tiles the generic one, in the same launch;
     # every epilogue kind wt_dbg_gemm can reach (plain, GELU, residual in place)
-    (4000, 3200, 48, 0, False), (4100, 3210, 64, 1, False), (5000, 2600, 256, 0, True), (12000, 1100, 64, 0, True)])
+    (4000, 3200, 48, 0, False), (4100, 3210, 64, 1, False), (5000, 2600, 256, 0, True), (12000, 1100, 64, 0, True),
+    # (one-round launches of 752 tiles with one and two K-steps per tile: fewer K-steps than pipeline stages)
+    (12000, 1000, 16, 0, False), (11900, 1024, 32, 1, False)])
 def test_gemm_many_tiles(lib, M, N, K, act, use_res):
     A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
     R = _rand(M, N, seed=4) if use_res else None
