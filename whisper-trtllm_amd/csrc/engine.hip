@@ -828,7 +828,9 @@ extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_
     for (;;) {
         mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
         const bool mine = (int)(mb >> 48) == e->epoch;
-        const int retired = mine ? (int)((mb >> 32) & 0xffff) : 0;
+        // the word carries the low 16 bits of the retired count: compare modulo 2^16 (a caller may have enqueued thousands of no-op
+        // steps through wt_decoder_steps before handing over to this loop)
+        const int retired = mine ? e->issued - (int)((unsigned)(e->issued - (int)((mb >> 32) & 0xffff)) & 0xffffu) : 0;
         if (mine && ((mb >> 31) & 1)) break;
         if (e->issued < max_steps && e->issued - retired <= lookahead) {
             int rc = enqueue_steps(e, 1, s);
@@ -843,7 +845,7 @@ extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_
             if (q != hipSuccess && q != hipErrorNotReady) return fail(WT_E_HIP, "wt_decoder_run: stream failed: %s", hipGetErrorString(q));
             if (q == hipSuccess) {        // idle stream: either the word is about to land, or the steps died without reporting
                 mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
-                const int r2 = (int)(mb >> 48) == e->epoch ? (int)((mb >> 32) & 0xffff) : 0;
+                const int r2 = (int)(mb >> 48) == e->epoch ? e->issued - (int)((unsigned)(e->issued - (int)((mb >> 32) & 0xffff)) & 0xffffu) : 0;
                 if (r2 < e->issued && spins > (8ll << 20)) return fail(WT_E_STATE, "wt_decoder_run: %d steps enqueued, %d reported", e->issued, r2);
             }
         }
