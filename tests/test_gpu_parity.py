@@ -110,6 +110,38 @@ def test_batches_larger_than_sixteen_are_chunked(wt):
         np.testing.assert_array_equal(ids[b, :len(one)], one)
 
 
+def test_length_sorted_batches_decode_like_single_utterances(wt):
+    """The variable-length workload end to end on a toy model: 11 utterances of different durations (log-mels padded behind their
+    audio), row i forced to stop at its own step, decoded in length-sorted batches of 4 (the default plan of run.py / cal_wer.py, incl.
+    the duration recovered from the padding) -- every utterance's ids equal the same utterance decoded ALONE, whatever batch and row
+    it landed in, and the host-side un-permutation returns dataset order."""
+    cfg = wt.synthetic.get_config("toy-short")
+    cfg["max_length"] = 24
+    weights = wt.synthetic.make_weights(cfg, 12)
+    enc, dec = _engines(wt, cfg, weights)
+    frames = 2 * cfg["max_source_positions"]
+    dur = [0.2 + 0.15 * ((7 * i) % 11) for i in range(11)]                  # seconds; all shorter than the toy window (1.92 s)
+    eos = [2 + (5 * i) % 17 for i in range(11)]
+    mel = torch.from_numpy(np.stack([wt.synthetic.make_mel_padded(cfg, 900 + i, dur[i]) for i in range(11)])).cuda()
+    lengths = wt.audio.valid_frames(mel)
+    assert lengths == [min(frames, int(round(d * 100))) for d in dur]
+    groups = wt.sharding.length_sorted_batches(lengths, 4)
+    assert sorted(i for g in groups for i in g) == list(range(11)) and [len(g) for g in groups] == [4, 4, 3]
+    assert all(lengths[g[0]] >= lengths[g[-1]] for g in groups) and lengths[groups[0][-1]] >= lengths[groups[1][0]]
+    got = {}
+    for g in groups:
+        ids = dec.generate(enc(mel[g]), force_eos_steps=[eos[i] for i in g]).cpu().numpy()
+        for row, i in enumerate(g):
+            got[i] = ids[row]
+    eos_id, pad = cfg["eos_token_id"], cfg["pad_token_id"]
+    for i in range(11):
+        one = dec.generate(enc(mel[i:i + 1]), force_eos_steps=[eos[i]]).cpu().numpy()[0]
+        n = len(one)
+        assert one[-1] == eos_id and n == eos[i] + 2                         # prompt + eos[i] tokens + the forced EOS
+        np.testing.assert_array_equal(got[i][:n], one)
+        assert (got[i][n:] == pad).all()                                     # behind its own EOS a row only pads
+
+
 def test_bitwise_reproducible_across_runs(wt):
     """No atomics on data and a fixed merge order in the split attention: two runs give bit-identical logits and ids."""
     z, cfg, weights, mel = load_case("toy-wide_b2")
