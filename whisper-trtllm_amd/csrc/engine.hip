@@ -106,8 +106,10 @@ struct wt_engine {
     int B = 0, max_length = 0, begin_index = 0, eos = 0, pad = 0, force_eos_step = -1, nsplit_self = 1, nsplit_cross = 4;
     float* trace = nullptr;
     hipStream_t own_stream = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    // step graphs: [0] every row attends (the only one a decode without early finishers ever replays), [1] finished rows stream no K/V
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    bool graph_ok[2] = {false, false};
     bool graph_valid = false, use_graph = true;
     int nt_loads = 1;  // stream weights and K/V with non-temporal loads (set per decode in wt_decoder_begin)
     // Session-compat shapes (set by infer_shapes)
@@ -160,8 +162,10 @@ extern "C" const char* wt_last_error(void) { return g_err; }
 extern "C" void wt_engine_close(wt_engine* e) {
     if (!e) return;
     DeviceGuard guard(e->device);
-    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
-    if (e->graph) hipGraphDestroy(e->graph);
+    for (int v = 0; v < 2; ++v) {
+        if (e->graph_exec[v]) hipGraphExecDestroy(e->graph_exec[v]);
+        if (e->graph[v]) hipGraphDestroy(e->graph[v]);
+    }
     for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) {
         timer_collect(*t);
         for (auto& pr : t->pool) {
@@ -507,6 +511,7 @@ struct StepIO {
     int kv_esz;                            // bytes per cache element: 4 (fp32; always on the Session path), 2 (resident caches of an fp16 engine)
     float* logits;                         // [B][V]
     int B, nsplit_self, nsplit_cross;
+    const int* alive;                      // skip-finished-rows graph of the fast path: per-row "unfinished" flags (DecAttnParams.alive)
     bool embed;                            // launch the input-embedding kernel (the fast path gets it from greedy_finish)
     // greedy fast path: masked argmax fused into the vocabulary GEMV (logits == nullptr: they never reach HBM unless traced)
     const SelectParams* argmax;            // or nullptr: write plain logits
@@ -541,7 +546,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
         break;
     case LP_SELF_ATTN:
         a.q = e->dq; a.kcache = sk; a.vcache = sv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = io.self_cap;
-        a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads; a.kv_half = kvh;
+        a.n_split = io.nsplit_self; a.fixed_len = 0; a.nt = e->nt_loads; a.kv_half = kvh; a.alive = io.alive;
         a.defer_merge = defer && io.nsplit_self == 2;   // both halves of the pair launch below merge the two partials while staging
         LAUNCH(launch_dec_attn(a, s));
         break;
@@ -562,6 +567,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     case LP_CROSS_ATTN: {  // cross attention over the encoder memory: K/V already resident
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
         a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t; a.kv_half = kvh;
+        a.alive = io.alive;
         a.defer_merge = defer && io.nsplit_cross == 2;  // the out-projection below merges the two split partials while staging them
                                                         // (more splits, i.e. batch < 8: the attention kernel merges its own, by ticket)
         hipEvent_t ta, tb;
@@ -747,8 +753,9 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     return WT_OK;
 }
 
-static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
+static int enqueue_fast_step(wt_engine* e, hipStream_t s, int variant = 0) {
     StepIO io;
+    io.alive = variant == 1 ? e->unfinished : nullptr;
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
     io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
@@ -772,12 +779,15 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s) {
     return WT_OK;
 }
 
-// enqueue n_steps decoder steps on `s` (the caller holds the device guard)
-static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s) {
+// enqueue n_steps decoder steps on `s` (the caller holds the device guard).  variant 1: the step graph in which finished rows stream
+// no K/V (wt_decoder_run switches to it once the mailbox reports a finished row; never with a logits trace, which records every
+// row's logits at every step as the reference computes them).
+static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant = 0) {
+    if (e->trace) variant = 0;
     e->issued += n_steps;
     if (e->profiling || !e->use_graph) {  // eager: per-kernel event timers need real launches
         for (int i = 0; i < n_steps; ++i) {
-            int rc = enqueue_fast_step(e, s);
+            int rc = enqueue_fast_step(e, s, variant);
             if (rc) return rc;
         }
         return WT_OK;
@@ -786,17 +796,23 @@ static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s) {
     // capturing executes nothing) and REPLAYED on the caller's stream: a replay on a second stream measured 5 % slower
     // per step (1.69 vs 1.60 ms, medium.en B=8) than on the stream the rest of the pass already runs on.
     if (!e->graph_valid) {
-        if (e->graph_exec) { hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-        if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
-        HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_fast_step(e, e->own_stream);
-        hipError_t ce = hipStreamEndCapture(e->own_stream, &e->graph);
-        if (rc) return rc;
-        if (ce != hipSuccess) return fail(WT_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-        HIPCHK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        for (int v = 0; v < 2; ++v) {
+            if (e->graph_exec[v]) { hipGraphExecDestroy(e->graph_exec[v]); e->graph_exec[v] = nullptr; }
+            if (e->graph[v]) { hipGraphDestroy(e->graph[v]); e->graph[v] = nullptr; }
+            e->graph_ok[v] = false;
+        }
         e->graph_valid = true;
     }
-    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(e->graph_exec, s));
+    if (!e->graph_ok[variant]) {
+        HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_fast_step(e, e->own_stream, variant);
+        hipError_t ce = hipStreamEndCapture(e->own_stream, &e->graph[variant]);
+        if (rc) return rc;
+        if (ce != hipSuccess) return fail(WT_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        HIPCHK(hipGraphInstantiate(&e->graph_exec[variant], e->graph[variant], nullptr, nullptr, 0));
+        e->graph_ok[variant] = true;
+    }
+    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(e->graph_exec[variant], s));
     return WT_OK;
 }
 
@@ -833,7 +849,10 @@ extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_
         const int retired = mine ? e->issued - (int)((unsigned)(e->issued - (int)((mb >> 32) & 0xffff)) & 0xffffu) : 0;
         if (mine && ((mb >> 31) & 1)) break;
         if (e->issued < max_steps && e->issued - retired <= lookahead) {
-            int rc = enqueue_steps(e, 1, s);
+            // a row has finished (the word's unfinished mask lost a bit): from here on replay the graph whose attention skips such rows
+            const unsigned full = (1u << e->B) - 1u;
+            const int variant = (mine && retired > 0 && ((unsigned)mb & 0xffffu) != full) ? 1 : 0;
+            int rc = enqueue_steps(e, 1, s, variant);
             if (rc) return rc;
             spins = 0;
             continue;
@@ -957,6 +976,7 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     io.ids = data; io.ids_ld = 1; io.self_k = nsk; io.self_v = nsv; io.self_cap = cache_len + 1;
     io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1; io.kv_esz = 4;
     io.nsplit_self = 1; io.nsplit_cross = pick_splits(1, e->H, S);
+    io.alive = nullptr;
     io.embed = true;
     io.argmax = nullptr; io.argmax_parts = nullptr;
     e->begun = false;  // the resident greedy state is clobbered by this call
@@ -1014,6 +1034,7 @@ extern "C" int wt_decoder_time_kernel(wt_engine* e, const char* which, int iters
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
     io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross; io.embed = false; io.argmax = nullptr; io.argmax_parts = nullptr;
+    io.alive = nullptr;
     struct ProfilingOff {   // no event records inside the capture; the caller's setting comes back on every exit path
         wt_engine* e; bool was;
         explicit ProfilingOff(wt_engine* e_) : e(e_), was(e_->profiling) { e->profiling = false; }

@@ -625,7 +625,7 @@ __device__ __forceinline__ float row8_allreduce_sum(float v) {   // sum over eac
 // PIPE: the U keys a stream takes per iteration are handled as two half-tiles with their own registers; the loads of one half are in
 // flight while the other is consumed (the same number of loads in flight as the plain form, but the exp / FMA work of a half-tile --
 // a fifth of an iteration with fp16 caches, a tenth with fp32 -- no longer sits between one tile's arrival and the next request).
-template <int U, bool NT, bool KVH, bool PIPE = false>
+template <int U, bool NT, bool KVH, bool PIPE = false, bool ALIVE = false>
 __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     constexpr int LPK = KVH ? 8 : 16;          // lanes per key
     constexpr int DPL = HEAD_DIM / LPK;        // head dims per lane: 8 or 4 (16 bytes of K or V either way)
@@ -738,6 +738,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
         const float rstd = rsqrtf(wave_allreduce_sum_d(sq) / d + 1e-5f);
 #pragma unroll
         for (int i = 0; i < DPL; ++i) q[i] = (q[i] - mean * r[i]) * rstd + t[i];
+    }
+    // A finished row pads whatever it computes (run.py:219-226 stops a batch-1 decode at its own EOS): in the step graph that
+    // wt_decoder_run switches to once a row has finished, such a row leaves here and streams no K/V.  (The test costs the dominant
+    // kernel 0.3-1.8 % when it sits in the all-rows-alive graph -- measured -- which is why that graph is built without it.)
+    if constexpr (ALIVE) {   // a compile-time form: the all-rows-alive graph runs the kernel exactly as it was
+        if (p.alive[b] == 0) return;   // block-uniform
     }
     float m = -INFINITY, l = 0.f;
     float acc[DPL];
@@ -886,6 +892,10 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     // 13.35 -> 12.84 (two splits) / 15.28 -> 13.49 (one); fp32 caches 19.87 vs 19.98 (no gain: a tenth of an iteration is arithmetic
     // there, a fifth with fp16 caches) -- so fp16 caches only.  A/B: WT_ATTN_PIPE=0|1 forces it off / on for both.
     static const int pipe = tuning_env("WT_ATTN_PIPE") ? atoi(tuning_env("WT_ATTN_PIPE")) : -1;
+    if (p.alive) {   // the skip-finished-rows step graph (non-temporal streaming forms only; others fall through to the plain kernels)
+        if (p.kv_half && nt && pipe != 0) { hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true, true>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
+        if (!p.kv_half && nt && pipe != 1) { hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, true>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
+    }
     if (p.kv_half) {
         if (nt && pipe != 0) hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true>), grid, dim3(256), 0, s, p);
         else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, true>), grid, dim3(256), 0, s, p);

@@ -108,6 +108,8 @@ struct DecAttnParams {
     const float* ln_r;     // [d] row sums of s.Wq.diag(gamma)
     const float* ln_t;     // [d] s.(Wq.beta + bq)
     int kv_half;           // kcache / vcache are IEEE half (fp16 decoder engines keep their RESIDENT caches in fp16; fp32 arithmetic)
+    const int* alive;      // optional [B]: rows with alive[b] == 0 (finished: they emit pad whatever their logits) stream no K/V; their
+                           // context / partials keep the previous step's (finite) values.  nullptr: every row attends.
 };
 
 // A/B tuning switches (WT_NSPLIT_CROSS, WT_GEMM_NO_DMA, ...; DESIGN.md "Tuning knobs") are lab tools, not part of the C-ABI's
