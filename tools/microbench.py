@@ -121,6 +121,11 @@ def bench_skinny(B=8, L=24):
         print(f"skinny N={N} K={K} xmode={xmode}: {us:7.2f} us  {N * K * 4 / us * 1e-3:7.1f} TB/s")
 
 
+def bench_skinny16(L=24):
+    """decode GEMVs at batch 16 (the K-split plan <16, 2, 8>)"""
+    bench_skinny(B=16, L=L)
+
+
 def bench_skinny_floor(B=8):
     """Fixed cost of a decode-step GEMV launch: tiny problem, and the real shapes with cache-resident weights."""
     for (N, K, xmode, n_rot) in ((64, 256, 0, 1), (1024, 1024, 0, 1), (1024, 1024, 1, 1), (4096, 1024, 1, 1), (1024, 4096, 0, 1), (4096, 1024, 1, 24)):
