@@ -784,11 +784,11 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s, int variant = 0) {
 // row's logits at every step as the reference computes them).
 static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant = 0) {
     if (e->trace) variant = 0;
-    e->issued += n_steps;
     if (e->profiling || !e->use_graph) {  // eager: per-kernel event timers need real launches
         for (int i = 0; i < n_steps; ++i) {
             int rc = enqueue_fast_step(e, s, variant);
             if (rc) return rc;
+            e->issued += 1;
         }
         return WT_OK;
     }
@@ -812,7 +812,10 @@ static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant =
         HIPCHK(hipGraphInstantiate(&e->graph_exec[variant], e->graph[variant], nullptr, nullptr, 0));
         e->graph_ok[variant] = true;
     }
-    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(e->graph_exec[variant], s));
+    for (int i = 0; i < n_steps; ++i) {
+        HIPCHK(hipGraphLaunch(e->graph_exec[variant], s));
+        e->issued += 1;   // counted only once it is really in the queue: wt_decoder_run compares it with the steps the mailbox reports
+    }
     return WT_OK;
 }
 
