@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-varlen", action="store_true", help="skip the variable-length (LibriSpeech-like) workload")
     ap.add_argument("--no-fp16-decoder", action="store_true", help="skip the fp16-engine (encoder + decoder) batch-16 measurement")
     ap.add_argument("--varlen-utterances", type=int, default=64, help="utterances per GPU in the variable-length workload")
+    ap.add_argument("--no-two-workers", action="store_true", help="skip the two-workers-per-GPU figures (WhisperPipeline)")
     ap.add_argument("--cpu-decode-steps", type=int, default=128, help="decoder steps timed on the CPU (about 10 s of CPU work in total)")
     ap.add_argument("--encoder-precision", default="float32", choices=["float32", "float16"],
                     help="float16 = BASELINE config 4 (fp16 encoder + fp32 decoder); the headline metric is float32")
@@ -88,8 +89,10 @@ def main():
     B, S, d, L, H, V = args.batch, cfg["max_source_positions"], cfg["d_model"], cfg["decoder_layers"], cfg["decoder_attention_heads"], cfg["vocab_size"]
     t0 = time.time()
     weights = w.synthetic.make_weights(cfg, args.seed)
-    enc = w.WhisperEncoderEngine(w.convert.build_encoder_engine(cfg, weights, precision=args.encoder_precision))
-    dec = w.WhisperDecoderEngine(w.convert.build_decoder_engine(cfg, weights), cfg)
+    enc_blob = w.convert.build_encoder_engine(cfg, weights, precision=args.encoder_precision)
+    dec_blob = w.convert.build_decoder_engine(cfg, weights)
+    enc = w.WhisperEncoderEngine(enc_blob)
+    dec = w.WhisperDecoderEngine(dec_blob, cfg)
     mel = torch.from_numpy(w.synthetic.make_mel(cfg, index=rank * B, batch=B)).cuda()
     if rank == 0:
         log(f"[bench] engines built in {time.time() - t0:.1f}s ({args.model}, B={B}/GPU, world {world})")
@@ -180,6 +183,35 @@ def main():
                                     "slot_utilisation": round(w.sharding.slot_utilisation(row_steps, by_length), 4)},
                   "note": "value = 30 s windows per second as in the headline; lengths modelled on LibriSpeech test-clean (no dataset on the box), "
                           "EOS forced per row; rank r uses seed r"}
+        if not args.no_two_workers:
+            # the same length-sorted batches handed to 2 and 4 WORKERS per GPU (runtime.WhisperPipeline: N engine pairs, N host threads,
+            # N streams): one worker's MFMA-bound encoder and launch-latency-bound decode fill the gaps of the others' decodes.
+            # ... and the headline's own passes (8 x 30 s, 447 decoder steps each) N at a time.  NOT the headline: `value` keeps ONE batch
+            # of 8 in flight per GPU, as the metric is quoted; this is N x 8 in flight (compare value_batch16_per_gpu).
+            mb = [vmel[g] for g in by_length]
+            kw = [{"force_eos_steps": [eos_steps[i] for i in g]} for g in by_length]
+            varlen["length_sorted_workers"], varlen["headline_passes_workers"] = {}, {}
+            for nw in (2, 4):
+                pipe = w.WhisperPipeline(enc_blob, dec_blob, cfg, workers=nw)
+                pipe.transcribe(mb[:nw], kw[:nw])
+                barrier()
+                t = time.perf_counter()
+                pipe.transcribe(mb, kw)
+                torch.cuda.synchronize()
+                el2 = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+                barrier()
+                varlen["length_sorted_workers"][str(nw)] = round(30.0 * n_utt * world / el2, 2)
+                n2 = nw * max(1, args.steps)
+                pipe.transcribe([mel] * nw)
+                barrier()
+                t = time.perf_counter()
+                pipe.transcribe([mel] * n2)
+                torch.cuda.synchronize()
+                el2h = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+                barrier()
+                varlen["headline_passes_workers"][str(nw)] = round(30.0 * B * world * n2 / el2h, 2)
+                del pipe
+            del mb
         del vmel
 
     # secondary figure: fp16 ENGINES (build_encoder.py / build_decoder.py --engine_precision float16): half GEMM / GEMV operands and
@@ -220,6 +252,9 @@ def main():
                    "value_n32_decode_steps": round(value_n32, 2),
                    "value_batch16_per_gpu": round(value_b16, 2) if value_b16 else None,
                    "value_varlen": varlen["length_sorted"]["value"] if varlen else None,
+                   "value_varlen_4_workers": varlen["length_sorted_workers"]["4"] if varlen and "length_sorted_workers" in varlen else None,
+                   "value_2_workers_per_gpu": varlen["headline_passes_workers"]["2"] if varlen and "headline_passes_workers" in varlen else None,
+                   "value_4_workers_per_gpu": varlen["headline_passes_workers"]["4"] if varlen and "headline_passes_workers" in varlen else None,
                    "value_fp16_decoder_b16": fp16["value"] if fp16 else None, "wer": None},
     }
     if varlen:

@@ -32,6 +32,8 @@ def parse_arguments():
     parser.add_argument("--batching", choices=["sorted", "dataset"], default="sorted",
                         help="sorted (default): length-aware batches -- utterances ordered by the audio duration recovered from the "
                              "log-mel's trailing padding, so a batch does not decode on behind one long row; dataset: contiguous order")
+    parser.add_argument("--workers", type=int, default=2, help="engine pairs per GPU, each on its own stream and host thread (1 = one batch in "
+                        "flight at a time; 2 fills the decode's launch-latency gaps with the other batch's work: ~1.4x)")
     parser.add_argument("--dist-backend", type=str, default=None, help="nccl (= RCCL) | gloo; default: nccl when every rank has its own GPU")
     parser.add_argument("--log_level", type=str, default="error")
     return parser.parse_args()
@@ -52,8 +54,8 @@ if __name__ == "__main__":
     torch.cuda.set_device(device)
     with open(os.path.join(args.engine_dir, "config.pkl"), "rb") as f:
         config = pickle.load(f)
-    enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
-    dec = tensorrt_llm.WhisperDecoderEngine(open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config)
+    pipe = tensorrt_llm.WhisperPipeline(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read(),
+                                        open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config, workers=max(1, args.workers))
     tok = WhisperTokenDecoder.from_dir(args.whisper)
     with open(args.cache, "rb") as f:
         dataset = pickle.load(f)
@@ -64,10 +66,11 @@ if __name__ == "__main__":
         begin, end = tensorrt_llm.sharding.utterance_shard(len(dataset), world, rank)   # this rank's contiguous shard
         groups = [list(range(b0, b1)) for b0, b1 in tensorrt_llm.sharding.batches(begin, end, args.batch)]
     indexed = []
-    for g in groups:
-        mel = torch.stack([torch.as_tensor(dataset[i][0], dtype=torch.float32) for i in g]).cuda()
-        ids = dec.generate(enc(mel)).cpu().tolist()
-        indexed += list(zip(g, tok.batch_decode(ids, skip_special_tokens=True)))
+    for c0 in range(0, len(groups), 64):      # host -> device in chunks of 64 batches (a log-mel is 0.96 MB), decoded `workers` at a time
+        chunk = groups[c0:c0 + 64]
+        mels = [torch.stack([torch.as_tensor(dataset[i][0], dtype=torch.float32) for i in g]).cuda() for g in chunk]
+        for g, ids in zip(chunk, pipe.transcribe(mels)):
+            indexed += list(zip(g, tok.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)))
     indexed = sorted(tensorrt_llm.sharding.gather_objects(indexed, dist))            # back to dataset order on the host
     hypotheses = [h for _, h in indexed]
     references = [t for _, t in dataset]

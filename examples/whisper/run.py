@@ -44,6 +44,7 @@ def parse_arguments():
     parser.add_argument("--max_length", type=int, default=None)
     parser.add_argument("--batching", choices=["sorted", "dataset"], default="sorted",
                         help="fast path: length-aware batches (by the audio duration recovered from the log-mel's trailing padding) or dataset order")
+    parser.add_argument("--workers", type=int, default=2, help="fast path: engine pairs per GPU, each on its own stream and host thread")
     parser.add_argument("--dist-backend", type=str, default=None, help="nccl (= RCCL) | gloo; default: nccl when every rank has its own GPU")
     parser.add_argument("--dump_ids", type=str, default=None, help="rank 0 writes the fast-path token ids as JSON (tests)")
     return parser.parse_args()
@@ -152,8 +153,8 @@ if __name__ == "__main__":
         mels = [torch.from_numpy(tensorrt_llm.synthetic.make_mel(config, index=args.synthetic_start + i, batch=1)).cuda() for i in range(args.synthetic)]
     results = {}
     if not args.session:
-        enc = tensorrt_llm.WhisperEncoderEngine(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read())
-        dec = tensorrt_llm.WhisperDecoderEngine(open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config)
+        pipe = tensorrt_llm.WhisperPipeline(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read(),
+                                            open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config, workers=max(1, args.workers))
         if args.batching == "sorted":
             lengths = [tensorrt_llm.audio.valid_frames(m)[0] for m in mels]
             groups = tensorrt_llm.sharding.length_sorted_batches(lengths, 8, world, rank)
@@ -166,8 +167,8 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             t0 = time.time()
             indexed = []
-            for g in groups:
-                indexed += list(zip(g, dec.generate(enc(torch.cat([mels[i] for i in g]))).cpu().tolist()))
+            for g, ids in zip(groups, pipe.transcribe([torch.cat([mels[i] for i in g]) for g in groups])):
+                indexed += list(zip(g, ids.cpu().tolist()))
             torch.cuda.synchronize()
             elapsed = tensorrt_llm.sharding.max_over_ranks(time.time() - t0, dist)
             ids = [row for _, row in sorted(tensorrt_llm.sharding.gather_objects(indexed, dist))]   # dataset order, on the host

@@ -142,6 +142,33 @@ def test_length_sorted_batches_decode_like_single_utterances(wt):
         assert (got[i][n:] == pad).all()                                     # behind its own EOS a row only pads
 
 
+@pytest.mark.parametrize("workers", [1, 2, 3])
+def test_pipeline_of_workers_equals_one_engine(wt, workers):
+    """runtime.WhisperPipeline: `workers` engine pairs on one GPU, each on its own stream and host thread, batches handed out
+    dynamically.  Whatever worker decodes a batch, its ids are BITWISE those of a single engine pair decoding the batches one after the
+    other (nothing is shared between workers; the kernels are deterministic), results come back in input order, per-batch arguments reach
+    their batch, and an error in a worker thread surfaces in the caller."""
+    cfg = wt.synthetic.get_config("toy-short")
+    cfg["max_length"] = 24
+    weights = wt.synthetic.make_weights(cfg, 13)
+    eb, db = wt.convert.build_encoder_engine(cfg, weights), wt.convert.build_decoder_engine(cfg, weights)
+    enc, dec = wt.WhisperEncoderEngine(eb), wt.WhisperDecoderEngine(db, cfg)
+    sizes = [8, 3, 8, 1, 5, 16, 2]
+    mels = [torch.from_numpy(wt.synthetic.make_mel(cfg, index=50 * k, batch=b)).cuda() for k, b in enumerate(sizes)]
+    kws = [{"force_eos_steps": [3 + (5 * k + r) % 15 for r in range(b)]} if k % 2 else {"max_length": 12 + k} for k, b in enumerate(sizes)]
+    want = [dec.generate(enc(m), **kw).cpu().numpy() for m, kw in zip(mels, kws)]
+    pipe = wt.WhisperPipeline(eb, db, cfg, workers=workers)
+    for _ in range(2):                                # engines are reused across calls
+        got = pipe.transcribe(mels, kws)
+        assert len(got) == len(want)
+        for g, w_ in zip(got, want):
+            np.testing.assert_array_equal(g.cpu().numpy(), w_)
+    assert pipe.transcribe([]) == []
+    with pytest.raises(ValueError):
+        pipe.transcribe(mels[:2] + [mels[0][:, :, :100]])          # a malformed batch: the worker's ValueError reaches the caller
+    np.testing.assert_array_equal(pipe.transcribe(mels[:1], kws[:1])[0].cpu().numpy(), want[0])   # and the pipeline still works
+
+
 def test_bitwise_reproducible_across_runs(wt):
     """No atomics on data and a fixed merge order in the split attention: two runs give bit-identical logits and ids."""
     z, cfg, weights, mel = load_case("toy-wide_b2")

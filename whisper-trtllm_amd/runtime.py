@@ -298,3 +298,68 @@ class WhisperDecoderEngine:
         t = _lib.KernelTimer()
         _lib.check(self.session._lib.wt_engine_get_timer(self.session.handle, which.encode(), ctypes.byref(t)), "wt_engine_get_timer")
         return t.ms_total, t.launches
+
+
+class WhisperPipeline:
+    """`workers` independent (encoder, decoder) engine pairs on ONE GPU, each driven by its own host thread on its own HIP stream.
+
+    Why: a greedy decode is a chain of ~170 dependent, launch-latency-bound kernels per token -- it leaves most of the chip idle
+    most of the time -- while the encoder is MFMA-bound.  Batches are independent (the reference transcribes one clip after the
+    other, run.py:262-290), so a second in-flight batch fills the first one's gaps: two workers of batch 8 measure ~1.4x one worker
+    on whisper-medium.en (434 vs 312 audio-s/s with 447-step decodes; DESIGN.md section 6 "Two workers per GPU").  Every worker is a
+    complete engine pair (own weights, workspace, resident KV cache: ~7 GB for medium.en fp32), so nothing is shared and no lock is
+    taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done)."""
+
+    def __init__(self, encoder_buffer, decoder_buffer, config: dict, workers: int = 2, device: Optional[int] = None):
+        import torch
+        if workers < 1:
+            raise ValueError("workers must be >= 1")
+        self.device = torch.cuda.current_device() if device is None else device
+        self.config = config
+        self.engines = [(WhisperEncoderEngine(encoder_buffer, self.device), WhisperDecoderEngine(decoder_buffer, config, self.device))
+                        for _ in range(workers)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(workers)]
+
+    def transcribe(self, mel_batches: Sequence[Any], gen_kwargs: Optional[Sequence[dict]] = None) -> List[Any]:
+        """Encoder + greedy decode of every batch `[b_i, n_mels, 2*S]` (b_i <= 16 per engine call; larger ones are chunked by
+        `generate`); returns the id tensors in the order of `mel_batches`.  `gen_kwargs[i]` are extra arguments of `generate` for
+        batch i (max_length, force_eos_steps, ...).  Blocks until every batch is done."""
+        import itertools
+        import threading
+
+        import torch
+        n = len(mel_batches)
+        if gen_kwargs is not None and len(gen_kwargs) != n:
+            raise ValueError("gen_kwargs needs one entry per batch")
+        results: List[Any] = [None] * n
+        errors: List[BaseException] = []
+        counter, lock = itertools.count(), threading.Lock()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))      # the caller's pending work on the inputs
+
+        def work(k: int):
+            try:
+                torch.cuda.set_device(self.device)
+                enc, dec = self.engines[k]
+                stream = self.streams[k]
+                stream.wait_event(ready)
+                with torch.cuda.stream(stream):
+                    while not errors:
+                        with lock:
+                            i = next(counter)
+                        if i >= n:
+                            break
+                        kw = gen_kwargs[i] if gen_kwargs is not None else {}
+                        results[i] = dec.generate(enc(mel_batches[i]), **kw)
+                stream.synchronize()
+            except BaseException as exc:   # surfaced in the caller's thread below
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(min(len(self.engines), max(n, 1)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
