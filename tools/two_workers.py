@@ -10,10 +10,11 @@ import whisper_trtllm_amd as w
 
 model = sys.argv[1] if len(sys.argv) > 1 else "whisper-medium.en"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 cfg = w.synthetic.get_config(model)
 weights = w.synthetic.make_weights(cfg, 0)
 eb, db = w.convert.build_encoder_engine(cfg, weights), w.convert.build_decoder_engine(cfg, weights)
-mels = [torch.from_numpy(w.synthetic.make_mel(cfg, index=8 * i, batch=8)).cuda() for i in range(passes)]
+mels = [torch.from_numpy(w.synthetic.make_mel(cfg, index=B * i, batch=B)).cuda() for i in range(passes)]
 for n in (1, 2, 3, 4):
     pipe = w.WhisperPipeline(eb, db, cfg, workers=n)
     pipe.transcribe(mels[:n])
@@ -22,5 +23,5 @@ for n in (1, 2, 3, 4):
     pipe.transcribe(mels)
     torch.cuda.synchronize()
     el = time.perf_counter() - t
-    print(f"{model}: {n} worker(s), {passes} passes of 8 x 30 s: {el:.3f} s  ({passes * 240 / el:.1f} audio-s/s)", flush=True)
+    print(f"{model}: {n} worker(s), {passes} passes of {B} x 30 s: {el:.3f} s  ({passes * 30 * B / el:.1f} audio-s/s)", flush=True)
     del pipe
