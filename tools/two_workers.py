@@ -15,7 +15,7 @@ cfg = w.synthetic.get_config(model)
 weights = w.synthetic.make_weights(cfg, 0)
 eb, db = w.convert.build_encoder_engine(cfg, weights), w.convert.build_decoder_engine(cfg, weights)
 mels = [torch.from_numpy(w.synthetic.make_mel(cfg, index=B * i, batch=B)).cuda() for i in range(passes)]
-for n in (1, 2, 3, 4):
+for n in ([int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else (1, 2, 3, 4)):
     pipe = w.WhisperPipeline(eb, db, cfg, workers=n)
     pipe.transcribe(mels[:n])
     torch.cuda.synchronize()
