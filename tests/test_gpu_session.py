@@ -142,6 +142,10 @@ def test_fast_path_argument_errors(wt):
         enc(torch.zeros(1, 80, 100, device="cuda"))                         # wrong frame count
     with pytest.raises(ValueError):
         dec.begin(hidden[:, :10])                                           # wrong encoder memory shape
+    with pytest.raises(ValueError, match="CUDA"):
+        enc(torch.from_numpy(wt.synthetic.make_mel(cfg, 0, 2)))             # a HOST tensor must never reach the C-ABI as a device pointer
+    with pytest.raises(ValueError, match="CUDA"):
+        dec.begin(hidden.cpu())
     with pytest.raises(RuntimeError, match="max_length"):
         dec.begin(hidden, max_length=cfg["max_target_positions"] + 5)       # beyond max_target_positions
     bad = dict(cfg)

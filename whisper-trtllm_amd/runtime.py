@@ -142,6 +142,8 @@ class WhisperEncoderEngine:
         i = self.session.info
         if mel.dtype != torch.float32 or mel.dim() != 3 or mel.shape[1] != i.n_mels or mel.shape[2] != 2 * i.max_source_positions:
             raise ValueError(f"mel must be float32 [B,{i.n_mels},{2 * i.max_source_positions}], got {tuple(mel.shape)} {mel.dtype}")
+        if not mel.is_cuda:   # the C-ABI takes DEVICE pointers: a host pointer would fault on the GPU
+            raise ValueError("mel must be a CUDA (ROCm) tensor: move it to the GPU first (there is no CPU execution path)")
         mel = mel.contiguous()
         out = torch.empty(mel.shape[0], i.max_source_positions, i.d_model, dtype=torch.float32, device=mel.device)
         stream = torch.cuda.current_stream().cuda_stream
@@ -200,6 +202,8 @@ class WhisperDecoderEngine:
         i = self.session.info
         if encoder_hidden.dtype != torch.float32 or tuple(encoder_hidden.shape[1:]) != (i.max_source_positions, i.d_model):
             raise ValueError(f"encoder_hidden must be float32 [B,{i.max_source_positions},{i.d_model}]")
+        if not encoder_hidden.is_cuda or (logits_trace is not None and not logits_trace.is_cuda):
+            raise ValueError("encoder_hidden / logits_trace must be CUDA (ROCm) tensors: the C-ABI takes device pointers")
         self._enc = encoder_hidden.contiguous()
         self._B = self._enc.shape[0]
         if force_eos_steps is not None and len(force_eos_steps) != self._B:
