@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include <map>
 #include <string>
@@ -843,7 +844,7 @@ extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_
     if (lookahead > 64) lookahead = 64;
     const int max_steps = e->max_length - 1;               // MaxLengthCriteria fires at the latest after this many steps
     unsigned long long mb = 0;
-    long long spins = 0;
+    int spins = 0, slices = 0;   // since the last launch: busy-wait iterations, then 20 us sleep slices
     for (;;) {
         mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
         const bool mine = (int)(mb >> 48) == e->epoch;
@@ -857,18 +858,27 @@ extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_
             const int variant = (mine && retired > 0 && ((unsigned)mb & 0xffffu) != full) ? 1 : 0;
             int rc = enqueue_steps(e, 1, s, variant);
             if (rc) return rc;
-            spins = 0;
+            spins = slices = 0;
             continue;
         }
         if (e->issued >= max_steps && retired >= e->issued) break;   // every possible step has retired (done is set with the last)
-        __builtin_ia32_pause();
-        if ((++spins & 0xfffff) == 0) {   // every ~ms of spinning: is the stream still alive?
+        // Wait for the word: spin briefly (it often lands within microseconds of a check), then sleep in 20 us slices -- a whole step
+        // (0.15-1.5 ms) is queued behind the running one, so the host has that long to enqueue the next, and N workers per GPU
+        // (runtime.WhisperPipeline) x 8 ranks need not burn N x 8 host cores.
+        if (spins < 2000) {
+            ++spins;
+            __builtin_ia32_pause();
+            continue;
+        }
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+        if (++slices % 64 == 0) {   // every few ms of waiting: is the stream still alive?
             const hipError_t q = hipStreamQuery(s);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(WT_E_HIP, "wt_decoder_run: stream failed: %s", hipGetErrorString(q));
-            if (q == hipSuccess) {        // idle stream: either the word is about to land, or the steps died without reporting
+            if (q == hipSuccess && slices > 4096) {   // an idle stream for > 0.1 s and the steps still unreported: they died without a word
                 mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
                 const int r2 = (int)(mb >> 48) == e->epoch ? e->issued - (int)((unsigned)(e->issued - (int)((mb >> 32) & 0xffff)) & 0xffffu) : 0;
-                if (r2 < e->issued && spins > (8ll << 20)) return fail(WT_E_STATE, "wt_decoder_run: %d steps enqueued, %d reported", e->issued, r2);
+                if (r2 < e->issued && !((mb >> 31) & 1)) return fail(WT_E_STATE, "wt_decoder_run: %d steps enqueued, %d reported", e->issued, r2);
             }
         }
     }
