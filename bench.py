@@ -363,11 +363,31 @@ def main():
                 idt = lg[:, -1].argmax(-1, keepdim=True)
                 t_steps.append(time.perf_counter() - t)
         step_avg = float(np.mean(t_steps[1:])) if len(t_steps) > 1 else t_steps[0]
-        total = t_enc + t_steps[0] + (args.max_length - 2) * step_avg
+        # later steps attend over a longer self cache: time a few steps at two more cache lengths (self K/V of that length fabricated --
+        # timing only) and integrate the per-step time piecewise-linearly over all max_length-1 steps
+        n_steps_total = args.max_length - 1
+        anchors = [(float(np.mean(range(1, max(2, len(t_steps))))), step_avg)]
+        with torch.no_grad():
+            for t_len in (n_steps_total // 2, n_steps_total - 8):
+                if past is None or t_len <= len(t_steps) + 8:
+                    continue
+                fake = tuple((torch.randn(sk.shape[0], sk.shape[1], t_len, sk.shape[3]) * 0.1, torch.randn(sv.shape[0], sv.shape[1], t_len, sv.shape[3]) * 0.1, ck, cv)
+                             for (sk, sv, ck, cv) in past)
+                ts = []
+                for _ in range(4):
+                    t = time.perf_counter()
+                    lg, fake = cpu_ref.decoder_forward(Wt, cfg, idt, h, fake)
+                    ts.append(time.perf_counter() - t)
+                anchors.append((float(t_len + 2), float(np.mean(ts[1:]))))
+                del fake
+        xs_, ys_ = [a for a, _ in anchors], [b for _, b in anchors]
+        per_step = np.interp(np.arange(1, n_steps_total), xs_, ys_)          # steps 1 .. n-1 (step 0 is timed on its own: it includes cross-KV)
+        total = t_enc + t_steps[0] + float(per_step.sum())
         out["cpu_baseline"] = {"value": round(30.0 / total, 3), "unit": "audio-seconds/second", "cores": cores, "kind": "port",
                                "sample": f"1 utterance: full encoder ({t_enc:.2f}s) + {args.cpu_decode_steps} decoder steps "
-                                         f"(first {t_steps[0]:.3f}s incl. cross-KV, then {step_avg * 1e3:.1f} ms/step), "
-                                         f"extrapolated to {args.max_length - 1} steps, batch 1 as in run.py:296-315"}
+                                         f"(first {t_steps[0]:.3f}s incl. cross-KV, then {step_avg * 1e3:.1f} ms/step) + 3 steps each at self-cache lengths "
+                                         + ", ".join(f"{int(a)}: {b * 1e3:.1f} ms" for a, b in anchors[1:]) +
+                                         f"; per-step time interpolated over all {n_steps_total} steps, batch 1 as in run.py:296-315"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
