@@ -270,3 +270,35 @@ def test_hot_kernels_do_not_spill(tmp_path):
                 seen += 1
                 assert int(m.group(1)) == 0, f"{name} spills {m.group(1)} bytes per lane"
     assert seen >= 30, seen
+
+
+def test_pipeline_worker_dispatch_host_logic():
+    """runtime.run_workers (the host side of WhisperPipeline.transcribe, no GPU): results in input order whatever worker produced
+    them, items handed out dynamically (a slow item does not hold the others back), setup / teardown once per thread, fewer items than
+    workers, and the first exception re-raised in the caller after every worker has returned."""
+    import threading
+    import time
+    from whisper_trtllm_amd.runtime import run_workers
+    seen, ups, downs = [], [], []
+    lock = threading.Lock()
+
+    def item(k, i):
+        time.sleep(0.05 if i == 0 else 0.001)       # item 0 is slow: its worker takes fewer items
+        with lock:
+            seen.append((k, i))
+        return i * i
+
+    out = run_workers(40, 3, item, setup=lambda k: ups.append(k), teardown=lambda k: downs.append(k))
+    assert out == [i * i for i in range(40)]
+    assert sorted(i for _, i in seen) == list(range(40)) and sorted(ups) == [0, 1, 2] and sorted(downs) == [0, 1, 2]
+    per_worker = {k: sum(1 for kk, _ in seen if kk == k) for k in range(3)}
+    slow = next(k for k, i in seen if i == 0)
+    assert per_worker[slow] < max(per_worker.values())                    # dynamic hand-out, not round-robin
+    assert run_workers(0, 4, item) == [] and run_workers(2, 8, item) == [0, 1]
+
+    def bad(k, i):
+        if i == 5:
+            raise KeyError("item 5")
+        return i
+    with pytest.raises(KeyError):
+        run_workers(50, 4, bad)

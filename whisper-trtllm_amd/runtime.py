@@ -328,42 +328,56 @@ class WhisperPipeline:
         """Encoder + greedy decode of every batch `[b_i, n_mels, 2*S]` (b_i <= 16 per engine call; larger ones are chunked by
         `generate`); returns the id tensors in the order of `mel_batches`.  `gen_kwargs[i]` are extra arguments of `generate` for
         batch i (max_length, force_eos_steps, ...).  Blocks until every batch is done."""
-        import itertools
-        import threading
-
         import torch
         n = len(mel_batches)
         if gen_kwargs is not None and len(gen_kwargs) != n:
             raise ValueError("gen_kwargs needs one entry per batch")
-        results: List[Any] = [None] * n
-        errors: List[BaseException] = []
-        counter, lock = itertools.count(), threading.Lock()
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))      # the caller's pending work on the inputs
 
-        def work(k: int):
-            try:
-                torch.cuda.set_device(self.device)
-                enc, dec = self.engines[k]
-                stream = self.streams[k]
-                stream.wait_event(ready)
-                with torch.cuda.stream(stream):
-                    while not errors:
-                        with lock:
-                            i = next(counter)
-                        if i >= n:
-                            break
-                        kw = gen_kwargs[i] if gen_kwargs is not None else {}
-                        results[i] = dec.generate(enc(mel_batches[i]), **kw)
-                stream.synchronize()
-            except BaseException as exc:   # surfaced in the caller's thread below
-                errors.append(exc)
+        def setup(k: int):
+            torch.cuda.set_device(self.device)
+            self.streams[k].wait_event(ready)
 
-        threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(min(len(self.engines), max(n, 1)))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        return results
+        def item(k: int, i: int):
+            enc, dec = self.engines[k]
+            with torch.cuda.stream(self.streams[k]):
+                return dec.generate(enc(mel_batches[i]), **(gen_kwargs[i] if gen_kwargs is not None else {}))
+
+        return run_workers(n, len(self.engines), item, setup=setup, teardown=lambda k: self.streams[k].synchronize())
+
+
+def run_workers(n_items: int, n_workers: int, item, setup=None, teardown=None) -> List[Any]:
+    """Host side of `WhisperPipeline.transcribe` (no GPU in here): `n_workers` threads take item indices 0 .. n_items-1 from a shared
+    counter (a worker takes the next item when it is done with its own: dynamic, not round-robin), `item(worker, index)` produces
+    result[index]; `setup(worker)` / `teardown(worker)` run once per thread.  The first exception stops the hand-out and is re-raised
+    in the caller's thread after every worker has returned."""
+    import itertools
+    import threading
+    results: List[Any] = [None] * n_items
+    errors: List[BaseException] = []
+    counter, lock = itertools.count(), threading.Lock()
+
+    def work(k: int):
+        try:
+            if setup is not None:
+                setup(k)
+            while not errors:
+                with lock:
+                    i = next(counter)
+                if i >= n_items:
+                    break
+                results[i] = item(k, i)
+            if teardown is not None:
+                teardown(k)
+        except BaseException as exc:   # surfaced in the caller's thread below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(max(1, min(n_workers, n_items)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
