@@ -21,8 +21,10 @@
  *   - calls are stream-ordered on the `hipStream_t` passed as `void* stream`; only wt_decoder_poll and
  *     wt_decoder_greedy synchronise (documented below).  First use with a new batch size allocates workspace.
  *   - every call runs on its handle's device and restores the caller's current device before returning.
- *   - one handle per device; a handle is NOT thread-safe (matches one IExecutionContext per Session,
- *     session.py:48); distinct handles may be driven concurrently.
+ *   - a handle is NOT thread-safe (matches one IExecutionContext per Session, session.py:48); distinct handles --
+ *     on different devices or several on ONE device -- may be driven concurrently from different host threads
+ *     (the Python side's WhisperPipeline runs N engine pairs per GPU that way; the library's lazily latched
+ *     state is atomic / initialised once).
  */
 #ifndef WHISPER_TRTLLM_AMD_H
 #define WHISPER_TRTLLM_AMD_H

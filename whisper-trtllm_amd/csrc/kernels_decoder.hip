@@ -879,11 +879,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     if (lane == 0) p.cnt[b * p.H + h] = 0;  // re-arm the ticket for the next launch (kernel boundary orders it)
 }
 hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
-    static int variant = -1;  // A/B override: WT_ATTN_VARIANT=0 forces default-policy loads, 1 forces non-temporal loads
-    if (variant < 0) {
+    // A/B override: WT_ATTN_VARIANT=0 forces default-policy loads, 1 forces non-temporal loads (2: as the engine asks).  A function-local
+    // static with an initialiser: latched once, thread-safe (handles of different host threads launch concurrently).
+    static const int variant = [] {
         const char* e = tuning_env("WT_ATTN_VARIANT");
-        variant = e ? atoi(e) : 2;
-    }
+        return e ? atoi(e) : 2;
+    }();
     const dim3 grid(p.n_split, p.H, p.B);
     const bool nt = variant == 2 ? p.nt != 0 : variant != 0;
     // non-temporal K/V loads: 18.6 vs 20.4 us per medium.en cross-attention launch; default policy only when a whole decode

@@ -523,7 +523,7 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
     }
     if ((p.K & 3) || (p.lda & 3) || (p.a_batch_stride & 3) || p.c_rows_per_batch < 1 || p.a_rows_per_batch < 1) return hipErrorInvalidValue;
     static PerDeviceFlag attr_set;
-    static int force_bk = 0;
+    static const int force_bk = [] { const char* ev = tuning_env("WT_GEMM_BK"); return ev ? atoi(ev) : 0; }();
     if (!attr_set.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<32>());
@@ -531,8 +531,6 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<16>());
         if (e != hipSuccess) return e;
-        const char* ev = tuning_env("WT_GEMM_BK");
-        force_bk = ev ? atoi(ev) : 0;
         attr_set.set();
     }
     const int nbx = (p.N + GBN - 1) / GBN, nby = (p.M + GBM - 1) / GBM;

@@ -1124,15 +1124,13 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
         return hipErrorInvalidValue;
     if (!kv && p.epi != EPI_ROWMAJOR) return hipErrorInvalidValue;
     static PerDeviceFlag attr_set;
-    static int bk = 32;
+    static const int bk = [] { const char* ev = tuning_env("WT_HGEMM_BK"); return (ev && (atoi(ev) == 32 || atoi(ev) == 64)) ? atoi(ev) : 32; }();
     if (!attr_set.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<64>());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<64>());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, hgemm_smem<32>());
         if (e != hipSuccess) return e;
-        const char* ev = tuning_env("WT_HGEMM_BK");
-        if (ev && (atoi(ev) == 32 || atoi(ev) == 64)) bk = atoi(ev);
         attr_set.set();
     }
     const int nbx = (p.N + HBN_ - 1) / HBN_, nby = (p.M + HBM_ - 1) / HBM_;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "host_logic.h"  // HEAD_DIM, BlobHeader / BlobTensor, EngineDims (host-only part, also built under ASan/UBSan)
 
 namespace wt {
@@ -130,11 +132,13 @@ __device__ __forceinline__ bool argmax_better(float v, int i, float best, int bi
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property: a launcher keeps one "done" flag per device
 // (`static PerDeviceFlag f; if (!f.get()) { ...set...; f.set(); }`), so a second device opened in the same process gets
 // its dynamic-LDS limit raised too.
+// Distinct handles may be driven from different host threads at once (runtime.WhisperPipeline does): the flag is atomic, and two
+// threads that both find it clear simply both set the (idempotent) attribute.
 struct PerDeviceFlag {
-    bool done[64] = {};
+    std::atomic<bool> done[64] = {};
     static int cur() { int dev = 0; (void)hipGetDevice(&dev); return dev & 63; }
-    bool get() const { return done[cur()]; }
-    void set() { done[cur()] = true; }
+    bool get() const { return done[cur()].load(std::memory_order_acquire); }
+    void set() { done[cur()].store(true, std::memory_order_release); }
 };
 
 // Every ABI entry point runs on its handle's device and leaves the CALLER's current device (torch's) as it found it.
