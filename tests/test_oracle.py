@@ -103,3 +103,35 @@ def test_engine_surface_partial_cross_cache():
     k0 = torch.nn.functional.linear(enc[:, :S - 10], W["model.decoder.layers.0.encoder_attn.k_proj.weight"])
     torch.testing.assert_close(nck[0, :, 10:], k0.view(1, S - 10, H, 64).transpose(1, 2)[0], atol=1e-5, rtol=1e-5)
     assert torch.isfinite(lg).all()
+
+
+def test_fp16_engine_modes_are_small_perturbations_of_the_pinned_fp32_oracle():
+    """The oracle's fp16_engine modes (the checker of the fp16 engines, tests/test_gpu_fp16_decoder.py / test_fp16_encoder_engine) are the
+    pinned fp32 restatement with roundings inserted: only weight MATRICES are rounded (biases, LayerNorm parameters and position tables
+    stay fp32, the tied vocabulary matrix stays tied), the outputs stay within fp16 rounding of the fp32 path, and with fp16_engine off
+    the functions are bit-for-bit the fp32 oracle the goldens pin."""
+    z, cfg, weights, mel = load_case("toy-short_b3")
+    w16 = cpu_ref.fp16_engine_weights(weights, encoder=True, decoder=True)
+    for k, v in weights.items():
+        is_matrix = k.endswith(".weight") and v.ndim >= 2 and "embed_positions" not in k
+        if is_matrix:
+            assert np.array_equal(w16[k], v.astype(np.float16).astype(np.float32)), k
+        else:
+            assert w16[k] is v or np.array_equal(w16[k], v), k
+    assert w16["proj_out.weight"] is w16["model.decoder.embed_tokens.weight"]
+    only_dec = cpu_ref.fp16_engine_weights(weights, decoder=True)
+    assert only_dec["model.encoder.layers.0.fc1.weight"] is weights["model.encoder.layers.0.fc1.weight"]
+    W, W16 = cpu_ref.to_torch(weights), cpu_ref.to_torch(w16)
+    x = torch.from_numpy(mel)
+    with torch.no_grad():
+        h32 = cpu_ref.encoder_forward(W, cfg, x)
+        assert torch.equal(h32, cpu_ref.encoder_forward(W, cfg, x, fp16_engine=False))
+        h16 = cpu_ref.encoder_forward(W16, cfg, x, fp16_engine=True)
+        scale = h32.abs().max().item()
+        err = (h16 - h32).abs().max().item()
+        assert 1e-5 * scale < err < 1e-2 * scale, (err, scale)           # rounded, but only at fp16 precision
+        ids32, lg32 = cpu_ref.greedy_search(W, cfg, h32, return_logits=True)
+        ids16, lg16 = cpu_ref.greedy_search(W16, cfg, h32, return_logits=True, fp16_engine=True)
+        n = min(lg32.shape[1], lg16.shape[1])
+        assert (lg16[:, :n] - lg32[:, :n]).abs().max().item() < 5e-2 * lg32.abs().max().item()
+    np.testing.assert_array_equal(ids32.numpy(), z["ids"])
