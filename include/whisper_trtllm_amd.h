@@ -82,6 +82,11 @@ typedef struct {
 /* (1) replaces Session.from_serialized_engine (session.py:54): parse the blob, upload weights to `device`.
  * Blobs are versioned (engine_pack.py VERSION); a blob written by another version is refused with WT_E_UNSUPPORTED. */
 int wt_engine_open(const void* blob, size_t nbytes, int device, wt_engine** out);
+/* (1b) a second handle on the SAME weights (TensorRT: one ICudaEngine, several IExecutionContexts -- session.py:48 creates one per
+ * Session): the read-only weight payload is shared and reference-counted, workspace / resident caches / step graphs are the new
+ * handle's own.  Lets N host threads drive N decodes on one device (distinct handles may run concurrently) at the cost of one copy
+ * of the weights.  The payload is freed when the last handle sharing it is closed, in any order. */
+int wt_engine_clone(const wt_engine* src, wt_engine** out);
 /* (2) engine teardown (TensorRT: ICudaEngine/IExecutionContext destructors). */
 void wt_engine_close(wt_engine* e);
 int wt_engine_get_info(const wt_engine* e, wt_engine_info* out);

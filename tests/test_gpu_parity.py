@@ -169,6 +169,38 @@ def test_pipeline_of_workers_equals_one_engine(wt, workers):
     np.testing.assert_array_equal(pipe.transcribe(mels[:1], kws[:1])[0].cpu().numpy(), want[0])   # and the pipeline still works
 
 
+def test_cloned_engines_share_weights_and_outlive_their_source(wt):
+    """wt_engine_clone: a second handle on the same device weights (own workspace / caches / graphs).  Cloning costs no second copy of
+    the payload, clones give bitwise the source's results, and the payload lives until the LAST handle sharing it is closed -- in any
+    order (the source first here)."""
+    import gc
+    cfg = wt.synthetic.get_config("whisper-tiny.en")          # ~150 MB of weights: visible in the device's free-memory figure
+    cfg["max_length"] = 8
+    weights = wt.synthetic.make_weights(cfg, 3)
+    enc = wt.WhisperEncoderEngine(wt.convert.build_encoder_engine(cfg, weights))
+    dec = wt.WhisperDecoderEngine(wt.convert.build_decoder_engine(cfg, weights), cfg)
+    mel = torch.from_numpy(wt.synthetic.make_mel(cfg, index=3, batch=2)).cuda()
+    want = dec.generate(enc(mel)).cpu().numpy()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    enc2, dec2 = enc.clone(), dec.clone()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 * 2**20, "a clone must not copy the weights"
+    np.testing.assert_array_equal(dec2.generate(enc2(mel)).cpu().numpy(), want)
+    np.testing.assert_array_equal(dec.generate(enc2(mel)).cpu().numpy(), want)     # handles mix freely
+    del enc, dec                                                                     # the source goes first ...
+    gc.collect()
+    np.testing.assert_array_equal(dec2.generate(enc2(mel)).cpu().numpy(), want)     # ... the clones still own the payload
+    enc3 = enc2.clone()
+    del enc2
+    gc.collect()
+    np.testing.assert_array_equal(dec2.generate(enc3(mel)).cpu().numpy(), want)
+    del enc3, dec2
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0                                     # everything is back once the last handle is closed
+
+
 def test_bitwise_reproducible_across_runs(wt):
     """No atomics on data and a fixed merge order in the split attention: two runs give bit-identical logits and ids."""
     z, cfg, weights, mel = load_case("toy-wide_b2")

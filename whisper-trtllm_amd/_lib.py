@@ -15,7 +15,7 @@ WT_NAME_LEN, WT_MAX_DIMS = 48, 6
 ABI_VERSION = 2
 
 EXPORTS = [
-    "wt_engine_open", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
+    "wt_engine_open", "wt_engine_clone", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
     "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_run", "wt_decoder_read_ids",
     "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
@@ -78,6 +78,7 @@ def load():
     lib.wt_last_error.restype = c_char_p
     lib.wt_abi_version.restype = c_int
     lib.wt_engine_open.argtypes = [c_void_p, c_size_t, c_int, POINTER(c_void_p)]
+    lib.wt_engine_clone.argtypes = [c_void_p, POINTER(c_void_p)]
     lib.wt_engine_close.argtypes = [c_void_p]
     lib.wt_engine_close.restype = None
     lib.wt_engine_get_info.argtypes = [c_void_p, POINTER(EngineInfo)]

@@ -11,6 +11,7 @@
 #include <time.h>
 
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -62,10 +63,23 @@ struct EvTimer {
     long long launches = 0;
 };
 
+// The weight payload of an engine in device memory: ONE allocation, read-only after wt_engine_open, shared (reference-counted) by the
+// handles wt_engine_clone makes from it -- N workers per GPU (runtime.WhisperPipeline) hold one copy of the weights and N workspaces.
+struct WeightStore {
+    char* base = nullptr;
+    int device = 0;
+    ~WeightStore() {
+        if (!base) return;
+        DeviceGuard guard(device);
+        hipFree(base);
+    }
+};
+
 struct wt_engine {
     int kind = 0, device = 0, precision = WT_F32;
     int d = 0, H = 0, L = 0, F = 0, C = 0, S = 0, T = 0, V = 0;
-    char* weights_base = nullptr;
+    std::shared_ptr<WeightStore> weights;
+    char* weights_base = nullptr;   // == weights->base
     std::map<std::string, DevTensor> w;
     // encoder
     std::vector<EncLayerW> enc_layers;
@@ -179,7 +193,7 @@ extern "C" void wt_engine_close(wt_engine* e) {
     if (e->mailbox) hipHostFree((void*)e->mailbox);
     if (e->enc_ws) hipFree(e->enc_ws);
     if (e->dec_ws) hipFree(e->dec_ws);
-    if (e->weights_base) hipFree(e->weights_base);
+    e->weights.reset();   // the last handle sharing the payload frees it
     delete e;
 }
 
@@ -208,7 +222,10 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
 
     // upload the tensor payload in one allocation
     const size_t payload = nbytes - hd.data_off;
-    hipError_t he = hipMalloc((void**)&e->weights_base, payload ? payload : 256);
+    e->weights = std::make_shared<WeightStore>();
+    e->weights->device = device;
+    hipError_t he = hipMalloc((void**)&e->weights->base, payload ? payload : 256);
+    e->weights_base = e->weights->base;
     if (he != hipSuccess) {
         int rc = fail(WT_E_NOMEM, "hipMalloc(%zu) for weights failed: %s", payload, hipGetErrorString(he));
         wt_engine_close(e);
@@ -298,6 +315,26 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         snprintf(g_err, sizeof g_err, "%s", keep.c_str());
         return WT_E_INVALID;
     }
+    *out = e;
+    return WT_OK;
+}
+
+extern "C" int wt_engine_clone(const wt_engine* src, wt_engine** out) {
+    if (!src || !out) return fail(WT_E_INVALID, "wt_engine_clone: null argument");
+    *out = nullptr;
+    wt_engine* e = new wt_engine();
+    e->kind = src->kind; e->device = src->device; e->precision = src->precision;
+    e->d = src->d; e->H = src->H; e->L = src->L; e->F = src->F; e->C = src->C; e->S = src->S; e->T = src->T; e->V = src->V;
+    e->weights = src->weights;            // shared, read-only
+    e->weights_base = src->weights_base;
+    e->w = src->w;
+    e->enc_layers = src->enc_layers;
+    e->conv1_w = src->conv1_w; e->conv1_b = src->conv1_b; e->conv2_w = src->conv2_w; e->conv2_b = src->conv2_b;
+    e->enc_pos = src->enc_pos; e->enc_ln_w = src->enc_ln_w; e->enc_ln_b = src->enc_ln_b;
+    e->dec_layers = src->dec_layers;
+    e->tok_emb = src->tok_emb; e->pos_emb = src->pos_emb; e->proj_w = src->proj_w; e->dec_ln_w = src->dec_ln_w; e->dec_ln_b = src->dec_ln_b;
+    e->w_half = src->w_half; e->kv_esz = src->kv_esz;
+    // workspace, resident caches, step graphs, streams, mailbox, timers: this handle's own, allocated on first use like a fresh engine's
     *out = e;
     return WT_OK;
 }

@@ -70,6 +70,16 @@ class Session:
     def from_serialized_engine(engine, device: Optional[int] = None) -> "Session":
         return Session()._init(engine, device)
 
+    def clone(self) -> "Session":
+        """A second execution context on the same weights (wt_engine_clone): own workspace / caches / graphs, shared read-only payload."""
+        other = Session()
+        other._lib = self._lib
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.wt_engine_clone(self._handle, ctypes.byref(handle)), "wt_engine_clone")
+        other._handle = handle
+        other.info = self.info
+        return other
+
     def __del__(self):
         try:
             if self._handle is not None and self._lib is not None:
@@ -132,10 +142,14 @@ class Session:
 class WhisperEncoderEngine:
     """mel f32 [B, n_mels, 2*S] on the GPU -> hidden f32 [B, S, d]; asynchronous on the current torch stream."""
 
-    def __init__(self, engine_buffer, device: Optional[int] = None):
-        self.session = Session.from_serialized_engine(engine_buffer, device)
+    def __init__(self, engine_buffer, device: Optional[int] = None, _session: Optional[Session] = None):
+        self.session = _session if _session is not None else Session.from_serialized_engine(engine_buffer, device)
         if self.session.info.kind != 1:
             raise ValueError("not a WhisperEncoder engine")
+
+    def clone(self) -> "WhisperEncoderEngine":
+        """Another engine on the same device weights (own workspace): for a second host thread / stream."""
+        return WhisperEncoderEngine(None, _session=self.session.clone())
 
     def __call__(self, mel):
         import torch
@@ -163,12 +177,16 @@ class WhisperDecoderEngine:
     `config` is the HF config dict the reference pickles into engine_dir/config.pkl (run.py:251) — the keys
     read are those of run.py:150-169, 273, 283-284."""
 
-    def __init__(self, engine_buffer, config: dict, device: Optional[int] = None):
-        self.session = Session.from_serialized_engine(engine_buffer, device)
+    def __init__(self, engine_buffer, config: dict, device: Optional[int] = None, _session: Optional[Session] = None):
+        self.session = _session if _session is not None else Session.from_serialized_engine(engine_buffer, device)
         if self.session.info.kind != 2:
             raise ValueError("not a WhisperDecoder engine")
         self.config = config
         self.max_batch = 16   # utterances per engine call (wt_decoder_begin); larger batches are chunked by generate()
+
+    def clone(self) -> "WhisperDecoderEngine":
+        """Another engine on the same device weights (own resident KV caches, step graphs, mailbox): for a second host thread / stream."""
+        return WhisperDecoderEngine(None, self.config, _session=self.session.clone())
 
     def _params(self, max_length, force_eos_step, logits_trace, force_eos_steps=None):
         cfg = self.config
@@ -311,8 +329,8 @@ class WhisperPipeline:
     most of the time -- while the encoder is MFMA-bound.  Batches are independent (the reference transcribes one clip after the
     other, run.py:262-290), so a second in-flight batch fills the first one's gaps: two workers of batch 8 measure ~1.4x one worker
     on whisper-medium.en (434 vs 312 audio-s/s with 447-step decodes; DESIGN.md section 6 "Two workers per GPU").  Every worker is a
-    complete engine pair (own weights, workspace, resident KV cache: ~7 GB for medium.en fp32), so nothing is shared and no lock is
-    taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done)."""
+    complete execution context (own workspace, resident KV cache, step graphs: ~4 GB for medium.en fp32) on ONE shared, read-only copy
+    of the weights (`wt_engine_clone`), so nothing mutable is shared and no lock is taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done)."""
 
     def __init__(self, encoder_buffer, decoder_buffer, config: dict, workers: int = 2, device: Optional[int] = None):
         import torch
@@ -320,8 +338,8 @@ class WhisperPipeline:
             raise ValueError("workers must be >= 1")
         self.device = torch.cuda.current_device() if device is None else device
         self.config = config
-        self.engines = [(WhisperEncoderEngine(encoder_buffer, self.device), WhisperDecoderEngine(decoder_buffer, config, self.device))
-                        for _ in range(workers)]
+        enc0, dec0 = WhisperEncoderEngine(encoder_buffer, self.device), WhisperDecoderEngine(decoder_buffer, config, self.device)
+        self.engines = [(enc0, dec0)] + [(enc0.clone(), dec0.clone()) for _ in range(workers - 1)]   # ONE copy of the weights on the device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(workers)]
 
     def transcribe(self, mel_batches: Sequence[Any], gen_kwargs: Optional[Sequence[dict]] = None) -> List[Any]:
