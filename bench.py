@@ -38,6 +38,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def under_rocprof() -> bool:
+    """rocprofv3 preloads its tool library into the benchmarked process.  Its kernel-trace interception of hipGraph replays is not safe
+    with SEVERAL host threads replaying graphs at once (a 4-worker run under `rocprofv3 --kernel-trace` segfaults inside the runtime;
+    the same run without the profiler is what the test suite and this benchmark do all the time), so the multi-worker legs are skipped
+    when the tool is loaded -- the kernels they launch are the ones the single-worker legs profile."""
+    return "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or any(k.startswith("ROCPROF_") for k in os.environ)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +71,12 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs round-robin")
     args = ap.parse_args()
+    if under_rocprof():
+        if args.workers > 1:
+            raise SystemExit("bench.py --workers N > 1 cannot run under rocprofv3 (see under_rocprof)")
+        if not args.no_two_workers:
+            log("[bench] rocprofv3 detected: skipping the multi-worker legs")
+        args.no_two_workers = True
 
     import numpy as np
     import torch

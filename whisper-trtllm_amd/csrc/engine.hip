@@ -12,6 +12,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -842,6 +843,11 @@ static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant =
         e->graph_valid = true;
     }
     if (!e->graph_ok[variant]) {
+        // Captures and instantiations are rare (once per engine and decode configuration) and serialised process-wide: several host
+        // threads drive their own handles concurrently (runtime.WhisperPipeline), and a multi-worker run under rocprofv3 crashed
+        // inside the runtime with two captures in flight at once.  Replays (hipGraphLaunch) stay concurrent.
+        static std::mutex capture_mutex;
+        std::lock_guard<std::mutex> lock(capture_mutex);
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_fast_step(e, e->own_stream, variant);
         hipError_t ce = hipStreamEndCapture(e->own_stream, &e->graph[variant]);

@@ -330,7 +330,9 @@ class WhisperPipeline:
     other, run.py:262-290), so a second in-flight batch fills the first one's gaps: two workers of batch 8 measure ~1.4x one worker
     on whisper-medium.en (434 vs 312 audio-s/s with 447-step decodes; DESIGN.md section 6 "Two workers per GPU").  Every worker is a
     complete execution context (own workspace, resident KV cache, step graphs: ~4 GB for medium.en fp32) on ONE shared, read-only copy
-    of the weights (`wt_engine_clone`), so nothing mutable is shared and no lock is taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done)."""
+    of the weights (`wt_engine_clone`), so nothing mutable is shared and no lock is taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done).
+    (Not under `rocprofv3 --kernel-trace`: the profiler's interception of graph replays from several host threads at once crashes in
+    the runtime; profile one worker -- the kernels are the same.)"""
 
     def __init__(self, encoder_buffer, decoder_buffer, config: dict, workers: int = 2, device: Optional[int] = None):
         import torch
