@@ -169,6 +169,30 @@ def test_pipeline_of_workers_equals_one_engine(wt, workers):
     np.testing.assert_array_equal(pipe.transcribe(mels[:1], kws[:1])[0].cpu().numpy(), want[0])   # and the pipeline still works
 
 
+def test_pipeline_workers_replan_concurrently(wt):
+    """Four workers on batches whose size keeps changing: workspaces are re-allocated and step graphs re-captured on one worker WHILE
+    the others replay theirs.  (Found by tools/soak.py in round 3: a synchronous hipMemset on the legacy stream in one worker's
+    workspace set-up was refused by the runtime while another worker captured its graph; workspace clears are stream-ordered now.)"""
+    cfg = wt.synthetic.get_config("toy-short")
+    cfg["max_length"] = 12
+    weights = wt.synthetic.make_weights(cfg, 14)
+    eb, db = wt.convert.build_encoder_engine(cfg, weights), wt.convert.build_decoder_engine(cfg, weights)
+    enc, dec = wt.WhisperEncoderEngine(eb), wt.WhisperDecoderEngine(db, cfg)
+    base = torch.from_numpy(wt.synthetic.make_mel(cfg, index=7, batch=16)).cuda()
+    sizes = [1 + (7 * i) % 16 for i in range(96)]
+    batches = [base[(3 * i) % 4:][:b] for i, b in enumerate(sizes)]
+    want = {}
+    for _ in range(2):
+        pipe = wt.WhisperPipeline(eb, db, cfg, workers=4)          # fresh workers: every first use allocates and captures
+        got = pipe.transcribe(batches)
+        for i, g in enumerate(got):
+            key = (sizes[i], (3 * i) % 4)
+            if key not in want:
+                want[key] = dec.generate(enc(batches[i])).cpu().numpy()
+            np.testing.assert_array_equal(g.cpu().numpy(), want[key])
+        del pipe
+
+
 def test_cloned_engines_share_weights_and_outlive_their_source(wt):
     """wt_engine_clone: a second handle on the same device weights (own workspace / caches / graphs).  Cloning costs no second copy of
     the payload, clones give bitwise the source's results, and the payload lives until the LAST handle sharing it is closed -- in any

@@ -349,7 +349,9 @@ extern "C" int wt_engine_get_info(const wt_engine* e, wt_engine_info* out) {
 }
 
 // ------------------------------------------------------------------------------------------------- encoder
-static int enc_reserve(wt_engine* e, int B) {
+// (workspace clears are stream-ordered on the CALLER's stream: a synchronous hipMemset runs on the legacy stream, which the runtime
+// refuses while ANOTHER host thread -- another worker's handle -- is capturing its step graph)
+static int enc_reserve(wt_engine* e, int B, hipStream_t s) {
     if (B <= e->enc_cap) return WT_OK;
     if (e->enc_ws) { hipFree(e->enc_ws); e->enc_ws = nullptr; e->enc_cap = 0; }
     const size_t Fr = 2 * (size_t)e->S, M = (size_t)B * e->S, d = e->d;
@@ -367,8 +369,8 @@ static int enc_reserve(wt_engine* e, int B) {
     e->melT_h = e->melT; e->c1_h = e->c1; e->x_h = e->xbuf; e->ffn_h = e->ffn;
     e->ctx_h = (char*)e->ffn + M * e->F * 2;  // second half of the ffn region (M*F*2 bytes >= M*d*2)
     // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
-    HIPCHK(hipMemset(e->melT, 0, ((size_t)B * (Fr + 2) * e->C + 4 * e->C) * 4));
-    HIPCHK(hipMemset(e->c1, 0, ((size_t)B * (Fr + 2) * d + 4 * d) * 4));
+    HIPCHK(hipMemsetAsync(e->melT, 0, ((size_t)B * (Fr + 2) * e->C + 4 * e->C) * 4, s));
+    HIPCHK(hipMemsetAsync(e->c1, 0, ((size_t)B * (Fr + 2) * d + 4 * d) * 4, s));
     e->enc_cap = B;
     return WT_OK;
 }
@@ -442,9 +444,9 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
     if (!mel || !out || B < 1) return fail(WT_E_INVALID, "wt_encoder_forward: bad arguments (batch %d)", B);
     DeviceGuard guard(e->device);
     HIPCHK(guard.err);
-    int rc = enc_reserve(e, B);
-    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    int rc = enc_reserve(e, B, s);
+    if (rc) return rc;
     const int S = e->S, Fr = 2 * S, d = e->d, C = e->C, M = B * S;
     if (e->precision == WT_F16) return encoder_forward_f16(e, mel, B, out, s);
     LAUNCH(launch_mel_transpose(mel, e->melT, B, C, Fr, s));
@@ -490,7 +492,7 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
 }
 
 // ------------------------------------------------------------------------------------------------- decoder
-static int dec_reserve(wt_engine* e, int B, int max_length) {
+static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s) {
     if (B <= e->dec_cap && max_length <= e->dec_maxlen_cap) return WT_OK;
     if (e->dec_ws) { hipFree(e->dec_ws); e->dec_ws = nullptr; e->dec_cap = 0; }
     e->graph_valid = false;
@@ -516,7 +518,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length) {
     e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask); e->force_rows = (int*)(b + o_frows);
     e->h_force_rows.clear();
     e->enc_h = e->w_half ? (void*)(b + o_ench) : nullptr;
-    HIPCHK(hipMemset(e->att_cnt, 0, (size_t)B * e->H * 4));  // arrival tickets start (and are left) at zero
+    HIPCHK(hipMemsetAsync(e->att_cnt, 0, (size_t)B * e->H * 4, s));  // arrival tickets start (and are left) at zero; stream-ordered (see enc_reserve)
     if (!e->h_state) HIPCHK(hipHostMalloc((void**)&e->h_state, sizeof(DecState), hipHostMallocDefault));
     if (!e->mailbox) {
         HIPCHK(hipHostMalloc((void**)&e->mailbox, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -711,9 +713,9 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
         return fail(WT_E_INVALID, "start/eos/pad token id outside the vocabulary");
     DeviceGuard guard(e->device);
     HIPCHK(guard.err);
-    int rc = dec_reserve(e, B, p->max_length);
-    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    int rc = dec_reserve(e, B, p->max_length, s);
+    if (rc) return rc;
     // token rules -> device tables (SuppressTokens / SuppressTokensAtBegin / ForceTokens).  The host images live in the engine:
     // when the rules are the ones of the previous decode (the usual case: one rule set per checkpoint) nothing is uploaded and
     // the call stays asynchronous; only a CHANGED rule set is uploaded, followed by one stream synchronisation.
@@ -1013,7 +1015,7 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
         return fail(WT_E_INVALID, "decoder run is missing a binding (need 7 input tensors besides the two masks and 5 outputs)");
     DeviceGuard guard(e->device);
     HIPCHK(guard.err);
-    int rc = dec_reserve(e, 1, e->T);
+    int rc = dec_reserve(e, 1, e->T, (hipStream_t)stream);
     if (rc) return rc;
     const int LH = e->L * e->H, S = e->S;
     const int cache_len = e->c_ms - 1 < e->c_s ? e->c_ms - 1 : e->c_s;  // model.py:278
