@@ -191,6 +191,24 @@ def test_pipeline_workers_replan_concurrently(wt):
                 want[key] = dec.generate(enc(batches[i])).cpu().numpy()
             np.testing.assert_array_equal(g.cpu().numpy(), want[key])
         del pipe
+    # ... and NEW engines / front-ends can be opened (weight upload, table upload) while workers are decoding and capturing: the
+    # library does no legacy-stream work (a synchronous hipMemcpy would be refused during another thread's capture)
+    import threading
+    pipe = wt.WhisperPipeline(eb, db, cfg, workers=3)
+    out = {}
+    th = threading.Thread(target=lambda: out.setdefault("got", pipe.transcribe(batches)))
+    th.start()
+    opened = 0
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        while th.is_alive() and opened < 12:
+            e2, d2 = wt.WhisperEncoderEngine(eb), wt.WhisperDecoderEngine(db, cfg)
+            fe = wt.audio.LogMelFrontend()
+            np.testing.assert_array_equal(d2.generate(e2(batches[1])).cpu().numpy(), want[(sizes[1], 3)])
+            assert torch.isfinite(fe(torch.zeros(1, 16000, device="cuda"))).all()
+            opened += 1
+    th.join()
+    assert opened >= 1 and len(out["got"]) == len(batches)
 
 
 def test_cloned_engines_share_weights_and_outlive_their_source(wt):

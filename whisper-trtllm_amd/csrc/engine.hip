@@ -232,7 +232,14 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         wt_engine_close(e);
         return rc;
     }
-    he = hipMemcpy(e->weights_base, (const char*)blob + hd.data_off, payload, hipMemcpyHostToDevice);
+    {   // upload on a private non-blocking stream, not the legacy stream: a synchronous hipMemcpy is refused by the runtime while another
+        // host thread (another handle's worker) is capturing its step graph
+        hipStream_t up = nullptr;
+        he = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipMemcpyAsync(e->weights_base, (const char*)blob + hd.data_off, payload, hipMemcpyHostToDevice, up);
+        if (he == hipSuccess) he = hipStreamSynchronize(up);
+        if (up) hipStreamDestroy(up);
+    }
     if (he != hipSuccess) {
         int rc = fail(WT_E_HIP, "weight upload failed: %s", hipGetErrorString(he));
         wt_engine_close(e);

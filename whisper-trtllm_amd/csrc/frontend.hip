@@ -191,9 +191,14 @@ extern "C" int wt_logmel_create(int device, int n_fft, int hop, int n_mels, int 
         wt_logmel_destroy(h);  // frees whichever tables were already allocated
         return wt_set_error(WT_E_NOMEM, "wt_logmel_create: table allocation failed");
     }
-    if (hipMemcpy(h->frag, frag.data(), nfrag * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->window, window, (size_t)n_fft * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->filt, filters, nf * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    hipStream_t up = nullptr;   // private non-blocking stream: no legacy-stream work while other host threads may be capturing graphs
+    bool ok = hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h->frag, frag.data(), nfrag * 8, hipMemcpyHostToDevice, up) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h->window, window, (size_t)n_fft * 8, hipMemcpyHostToDevice, up) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h->filt, filters, nf * 4, hipMemcpyHostToDevice, up) == hipSuccess;
+    ok = ok && hipStreamSynchronize(up) == hipSuccess;
+    if (up) hipStreamDestroy(up);
+    if (!ok) {
         wt_logmel_destroy(h);
         return wt_set_error(WT_E_HIP, "wt_logmel_create: table upload failed");
     }
