@@ -3,7 +3,11 @@
 // only include/whisper_trtllm_amd.h and the HIP runtime for device buffers.
 //
 //   hipcc -O2 -Iinclude examples/c/wt_greedy.cpp -Lwhisper-trtllm_amd/lib -lwhisper_trtllm_amd -Wl,-rpath,$PWD/whisper-trtllm_amd/lib -o wt_greedy
-//   ./wt_greedy WhisperEncoder.engine WhisperDecoder.engine mel.f32 <batch> rules.txt
+//   ./wt_greedy WhisperEncoder.engine WhisperDecoder.engine mel.f32 <batch> rules.txt [workers]
+//
+// With `workers` > 1 the same batch is decoded by that many host threads at once, each on its own clone of the two engines
+// (wt_engine_clone: one copy of the weights, own workspace / caches / graphs) and its own stream -- distinct handles may be driven
+// concurrently -- and the program fails unless every worker produced the same ids.
 //
 // rules.txt (whitespace separated integers): decoder_start eos pad max_length begin_index
 //   n_suppress s_1 .. s_n   n_begin_suppress b_1 .. b_n   n_forced (index token)_1 .. (index token)_n
@@ -11,6 +15,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "whisper_trtllm_amd.h"
@@ -30,9 +36,32 @@ static std::vector<char> read_file(const char* path) {
 #define WT(call) do { int rc_ = (call); if (rc_ != WT_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, wt_last_error()); return 1; } } while (0)
 #define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
 
+// encoder + greedy decode of one batch on one pair of handles and one stream; ids (batch x max_length) and the length come back
+static int decode_once(wt_engine* enc, wt_engine* dec, const wt_engine_info& ei, const std::vector<char>& mel, int batch, const wt_greedy_params& gp,
+                       std::vector<int32_t>* ids_out, int* len_out) {
+    hipStream_t stream;
+    HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    float *d_mel = nullptr, *d_hidden = nullptr;
+    int32_t* d_ids = nullptr;
+    HIP(hipMalloc((void**)&d_mel, mel.size()));
+    HIP(hipMalloc((void**)&d_hidden, (size_t)batch * ei.max_source_positions * ei.d_model * sizeof(float)));
+    HIP(hipMalloc((void**)&d_ids, (size_t)batch * gp.max_length * sizeof(int32_t)));
+    HIP(hipMemcpyAsync(d_mel, mel.data(), mel.size(), hipMemcpyHostToDevice, stream));
+    WT(wt_encoder_forward(enc, d_mel, batch, d_hidden, stream));
+    WT(wt_decoder_greedy(dec, d_hidden, batch, &gp, d_ids, len_out, stream));
+    ids_out->resize((size_t)batch * gp.max_length);
+    HIP(hipMemcpyAsync(ids_out->data(), d_ids, ids_out->size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d_mel); (void)hipFree(d_hidden); (void)hipFree(d_ids);
+    (void)hipStreamDestroy(stream);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 6) { fprintf(stderr, "usage: %s <encoder.engine> <decoder.engine> <mel.f32> <batch> <rules.txt>\n", argv[0]); return 2; }
+    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s <encoder.engine> <decoder.engine> <mel.f32> <batch> <rules.txt> [workers]\n", argv[0]); return 2; }
     const int batch = atoi(argv[4]);
+    const int workers = argc == 7 ? atoi(argv[6]) : 1;
+    if (workers < 1 || workers > 16) { fprintf(stderr, "workers must be 1..16\n"); return 2; }
     std::vector<char> enc_blob = read_file(argv[1]), dec_blob = read_file(argv[2]), mel = read_file(argv[3]);
 
     std::vector<int> rules;
@@ -49,34 +78,42 @@ int main(int argc, char** argv) {
     gp.forced_decoder_ids = forced.data(); gp.n_forced = (int)forced.size() / 2;
     gp.force_eos_step = -1; gp.logits_trace = nullptr; gp.force_eos_steps = nullptr;
 
-    wt_engine *enc = nullptr, *dec = nullptr;
-    WT(wt_engine_open(enc_blob.data(), enc_blob.size(), 0, &enc));
-    WT(wt_engine_open(dec_blob.data(), dec_blob.size(), 0, &dec));
+    std::vector<wt_engine*> encs((size_t)workers, nullptr), decs((size_t)workers, nullptr);
+    WT(wt_engine_open(enc_blob.data(), enc_blob.size(), 0, &encs[0]));
+    WT(wt_engine_open(dec_blob.data(), dec_blob.size(), 0, &decs[0]));
+    for (int k = 1; k < workers; ++k) {            // further execution contexts on the SAME device weights
+        WT(wt_engine_clone(encs[0], &encs[(size_t)k]));
+        WT(wt_engine_clone(decs[0], &decs[(size_t)k]));
+    }
     wt_engine_info ei;
-    WT(wt_engine_get_info(enc, &ei));
+    WT(wt_engine_get_info(encs[0], &ei));
     const size_t mel_floats = (size_t)batch * ei.n_mels * 2 * ei.max_source_positions;
     if (mel.size() != mel_floats * sizeof(float)) { fprintf(stderr, "mel file holds %zu bytes, expected %zu\n", mel.size(), mel_floats * sizeof(float)); return 2; }
 
-    hipStream_t stream;
-    HIP(hipStreamCreate(&stream));
-    float *d_mel = nullptr, *d_hidden = nullptr;
-    int32_t* d_ids = nullptr;
-    HIP(hipMalloc((void**)&d_mel, mel.size()));
-    HIP(hipMalloc((void**)&d_hidden, (size_t)batch * ei.max_source_positions * ei.d_model * sizeof(float)));
-    HIP(hipMalloc((void**)&d_ids, (size_t)batch * gp.max_length * sizeof(int32_t)));
-    HIP(hipMemcpyAsync(d_mel, mel.data(), mel.size(), hipMemcpyHostToDevice, stream));
-    WT(wt_encoder_forward(enc, d_mel, batch, d_hidden, stream));
-    int out_len = 0;
-    WT(wt_decoder_greedy(dec, d_hidden, batch, &gp, d_ids, &out_len, stream));
-    std::vector<int32_t> ids((size_t)batch * gp.max_length);
-    HIP(hipMemcpy(ids.data(), d_ids, ids.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<std::vector<int32_t>> ids((size_t)workers);
+    std::vector<int> lens((size_t)workers, 0), rcs((size_t)workers, 0);
+    std::vector<std::thread> threads;
+    for (int k = 1; k < workers; ++k)
+        threads.emplace_back([&, k] {
+            for (int rep = 0; rep < 3 && rcs[(size_t)k] == 0; ++rep)      // a few decodes per worker: graphs are captured, then replayed
+                rcs[(size_t)k] = decode_once(encs[(size_t)k], decs[(size_t)k], ei, mel, batch, gp, &ids[(size_t)k], &lens[(size_t)k]);
+        });
+    for (int rep = 0; rep < (workers > 1 ? 3 : 1) && rcs[0] == 0; ++rep) rcs[0] = decode_once(encs[0], decs[0], ei, mel, batch, gp, &ids[0], &lens[0]);
+    for (auto& t : threads) t.join();
+    for (int k = 0; k < workers; ++k) {
+        if (rcs[(size_t)k]) return 1;
+        if (lens[(size_t)k] != lens[0] || memcmp(ids[(size_t)k].data(), ids[0].data(), ids[0].size() * sizeof(int32_t)) != 0) {
+            fprintf(stderr, "worker %d decoded different ids than worker 0\n", k);
+            return 3;
+        }
+    }
     for (int b = 0; b < batch; ++b) {
-        for (int t = 0; t < out_len; ++t) printf(t ? " %d" : "%d", ids[(size_t)b * gp.max_length + t]);
+        for (int t = 0; t < lens[0]; ++t) printf(t ? " %d" : "%d", ids[0][(size_t)b * gp.max_length + t]);
         printf("\n");
     }
-    (void)hipFree(d_mel); (void)hipFree(d_hidden); (void)hipFree(d_ids);
-    wt_engine_close(enc);
-    wt_engine_close(dec);
-    (void)hipStreamDestroy(stream);
+    for (int k = workers - 1; k >= 0; --k) {       // any order: the weight payload is freed with the last handle that shares it
+        wt_engine_close(encs[(size_t)k]);
+        wt_engine_close(decs[(size_t)k]);
+    }
     return 0;
 }

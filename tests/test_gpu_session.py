@@ -304,6 +304,12 @@ def test_plain_c_host_of_the_c_abi(wt, tmp_path):
     want = z["ids"]
     np.testing.assert_array_equal(got, want[:, :got.shape[1]])
     assert got.shape[0] == want.shape[0] and (want[:, got.shape[1]:] == cfg["pad_token_id"]).all()
+    # the same program with 4 host threads on clones of the two engines (wt_engine_clone, std::thread, one stream each): it exits
+    # non-zero unless every worker decoded the same ids
+    out4 = subprocess.run([exe, str(tmp_path / "enc.engine"), str(tmp_path / "dec.engine"), str(tmp_path / "mel.f32"), str(mel.shape[0]),
+                           str(tmp_path / "rules.txt"), "4"], capture_output=True, text=True, timeout=300)
+    assert out4.returncode == 0, out4.stderr[-2000:]
+    assert out4.stdout == out.stdout
 
 
 def _write_engine_dir(wt, tmp_path, cfg, weights):

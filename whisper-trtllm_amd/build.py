@@ -67,7 +67,7 @@ def build_c_example(verbose: bool = False) -> str:
     newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(root, "include", "whisper_trtllm_amd.h")), os.path.getmtime(LIB_PATH))
     if os.path.exists(exe) and os.path.getmtime(exe) >= newest:
         return exe
-    cmd = [_hipcc(), "-O2", "-I" + os.path.join(root, "include"), src, "-L" + LIB_DIR, "-lwhisper_trtllm_amd",
+    cmd = [_hipcc(), "-O2", "-pthread", "-I" + os.path.join(root, "include"), src, "-L" + LIB_DIR, "-lwhisper_trtllm_amd",
            "-Wl,-rpath,$ORIGIN/../../whisper-trtllm_amd/lib", "-o", exe]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
