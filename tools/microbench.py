@@ -160,6 +160,33 @@ def bench_gemm_shapes():
         print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_gemm_rounds():
+    """fp32 GEMM: how much of the distance to the MFMA peak is per-launch (ramp + uneven finish of the co-resident workgroups)?  Same
+    N, K with M = exactly 1, 2, 4, 8, 16 rounds of the chip's 768 workgroup slots (M = 12000 is the encoder's 0.98 / 2.9 / 3.9 rounds)."""
+    for (N, K) in ((1024, 1024), (1024, 4096), (4096, 1024)):
+        for rounds in (1, 2, 4, 8, 16):
+            M = rounds * 768 * 128 * 128 // N
+            if M * max(N, K) > (1 << 29):
+                continue
+            A = torch.randn(M, K, device="cuda")
+            W = torch.randn(4, N, K, device="cuda") * 0.03
+            bias = torch.zeros(N, device="cuda")
+            C = torch.empty(M, N, device="cuda")
+            us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, 0, ST()), 4, iters=5)
+            print(f"gemm M={M} N={N} K={K} ({rounds} rounds of 768 tiles): {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
+
+
+def bench_gemm_steady():
+    """fp32 GEMM at 8 rounds of the chip (per-launch effects amortised): the steady-state rate, for the WT_GEMM_ABLATE probes"""
+    for (M, N, K) in ((98304, 1024, 1024), (24576, 1024, 4096)):
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(4, N, K, device="cuda") * 0.03
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, 0, ST()), 4, iters=5)
+        print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s (if it were the full product)")
+
+
 def bench_gemm_fixed(M=12000, N=1024):
     """fixed per-tile cost of the fp32 GEMM: K sweep at constant output size (752 tiles = one round)"""
     for K in (16, 64, 256, 512, 1024, 2048, 4096):
@@ -205,6 +232,31 @@ def bench_gemm_f16_variants():
                 us = timeit(fn, 4, iters=5)
                 row.append(f"v{variant} {us:7.1f} us {2.0 * M * N * K / us * 1e-6:6.0f} TF")
             print(f"gemm_f16 M={M} N={N} K={K} act={act} out_half={oh}: " + " | ".join(row))
+
+
+def bench_gemm_vs_library():
+    """Yardstick, not a product path: the vendor library (torch.nn.functional.linear -> hipBLASLt / rocBLAS) on the encoder's GEMM
+    shapes beside the engine's own kernels.  The library rows are the PLAIN product (bias only, no GELU / residual / fp16-cast
+    epilogue work beyond what F.linear does); the engine rows run the epilogue the encoder uses on that shape."""
+    import torch.nn.functional as F
+    for dt, Ms in ((torch.float32, (12000,)), (torch.float16, (12000, 24000))):
+        for M in Ms:
+            for (N, K) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
+                A = torch.randn(M, K, device="cuda").to(dt)
+                W = (torch.randn(4, N, K, device="cuda") * 0.03).to(dt)
+                bias = torch.zeros(N, device="cuda")
+                bias_l = bias.to(dt)
+                out_l = torch.empty(M, N, device="cuda", dtype=dt)
+                us_lib = timeit(lambda i: torch.addmm(bias_l, A, W[i].t(), out=out_l), 4, iters=5)
+                if dt == torch.float32:
+                    C = torch.empty(M, N, device="cuda")
+                    us = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, 0, ST()), 4, iters=5)
+                else:
+                    oh = 1 if N >= 2048 else 0
+                    C = torch.empty(M, N, device="cuda", dtype=torch.float16 if oh else torch.float32)
+                    us = timeit(lambda i: lib.wt_dbg_gemm_f16(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, 0, oh, ST()), 4, iters=5)
+                tf = lambda u: 2.0 * M * N * K / u * 1e-6
+                print(f"{str(dt)[6:]:8s} M={M} N={N} K={K}: engine {us:7.1f} us {tf(us):7.1f} TF | library {us_lib:7.1f} us {tf(us_lib):7.1f} TF")
 
 
 def bench_gemm_f16_v4(M=24000):

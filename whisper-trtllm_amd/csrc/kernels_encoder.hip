@@ -6,6 +6,7 @@
 // :48-66 (WhisperEncoderLayer), layers/attention.py:216-350; numerics follow the bundled HF oracle
 // modeling_whisper.py:569-593, :632-641, :992-1011 (erf GELU, q scaled before QK^T).
 #include "wt_common.h"
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -392,15 +393,20 @@ __global__ __launch_bounds__(256, GBK == 32 ? 2 : 3) void gemm_f32_kernel(const 
 // BN = 64: a 128x64 block tile (wave tile 64x32, W stage half used) for launches whose 128x128 tiling fills the chip's 768 workgroup
 // slots badly (small.en's N = 768: 564 tiles) -- half-size tiles fill the last round better; same stages, same LDS footprint
 // (three workgroups per CU either way).
-template <bool STAMP, int BN>
-__global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p) {
-    constexpr int STAGES = 3;
+// KSUB = 2: a stage holds TWO such 16-wide K tiles (32 KiB), two stages, two workgroups per CU: one wait + barrier per 32 of K instead
+// of per 16, the DMA of step kt+1 issued right after the barrier that opens step kt (its stage was read during step kt-1).
+// ABLATE (timing probes only, results are garbage; WT_TUNING=1 WT_GEMM_ABLATE=n): bit 0 no LDS-DMA in the loop, bit 1 no fragment
+// reads (register constants instead), bit 2 no barrier, bit 3 no MFMA, bit 4 every DMA re-fetches K tiles 0 / 1 (cache-hot sources).
+template <bool STAMP, int BN, int KSUB = 1, int ABLATE = 0>
+__global__ __launch_bounds__(256, KSUB == 2 ? 2 : 3) void gemm_f32_dma_kernel(const GemmParams p) {
+    constexpr int STAGES = KSUB == 2 ? 2 : 3;
+    constexpr int AHEAD = STAGES - 1;      // K steps in flight beyond the one being multiplied
     constexpr int BK = 16;
     constexpr int TJ = BN / 64;            // 32-column MFMA tiles per wave
     long long t_start = 0, t_first = 0, t_loop = 0;   // probe build: wall-clock stamps (100 MHz)
     if (STAMP) t_start = wall_clock64();
-    __shared__ __attribute__((aligned(1024))) float smem[STAGES][2][GBM * BK];  // [stage][A | W][row * 16 + pos * 4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES][KSUB][2][GBM * BK];  // [stage][K sub-tile][A | W][row * 16 + pos * 4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -419,26 +425,43 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
 
     // DMA map: wave w, pass j fills rows j*64 + w*16 .. +15; lane -> (row lane >> 2, chunk position lane & 3)
     const int r_local = lane >> 2, csrc = (lane & 3) ^ ((r_local >> 2) & 3);
-    const float* aptr[2];
-    const float* wptr[2];
+    // per-lane BYTE offsets of the source rows (32 bits: launch_gemm_f32 checks that the operands span < 4 GiB); the K step's column
+    // offset is wave-uniform and goes into the scalar base, and the LDS destination is scalar as well (`wave` is read through
+    // readfirstlane), so a request is `s_add m0 | global_load_lds v_off, s[base]` with no vector ALU work between the MFMAs
+    unsigned aoff[2], woff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = j * 64 + wave * 16 + r_local;
         const int m = min(m0 + row, p.M - 1);
         const int bb = m / p.a_rows_per_batch;
-        aptr[j] = p.A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 4;
+        aoff[j] = (unsigned)(((long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 4) * 4);
         const int n = min(n0 + row, p.N - 1);   // (BN = 64: only j = 0 is used)
-        wptr[j] = p.W + (long long)n * p.K + csrc * 4;
+        woff[j] = (unsigned)(((long long)n * p.K + csrc * 4) * 4);
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // (inline asm: from the builtin hipcc selects the 64-bit VECTOR address form and spends a v_lshl_add_u64 per request, and when the
+    //  LDS address is not provably scalar also a v_readfirstlane -- vector ALU work in front of every tile's MFMAs)
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)(&smem[0][0][0][0]) + (unsigned)wave * (16 * BK * 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 on the clobber list: it is written and consumed inside the one statement
     auto dma = [&](const int stage, const int kt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 64 + wave * 16) * BK]), 16, 0, 0);
-            if (j < TJ) __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 64 + wave * 16) * BK]), 16, 0, 0);
+        for (int ks = 0; ks < KSUB; ++ks) {
+            const char* ab = reinterpret_cast<const char*>(p.A) + (long long)(kt * KSUB + ks) * (BK * 4);   // wave-uniform
+            const char* wb = reinterpret_cast<const char*>(p.W) + (long long)(kt * KSUB + ks) * (BK * 4);
+            const unsigned st = lds_base + (unsigned)((stage * KSUB + ks) * (2 * GBM * BK * 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :: "s"(st + (unsigned)(j * 64 * BK * 4)), "v"(aoff[j]), "s"(ab) : "memory", "m0");
+                if (j < TJ)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                                 :: "s"(st + (unsigned)(GBM * BK * 4 + j * 64 * BK * 4)), "v"(woff[j]), "s"(wb) : "memory", "m0");
+            }
         }
     };
+#pragma clang diagnostic pop
 
     // fragment reads: rows wr*64 + l31 (+32) of A, wc*64 + l31 (+32) of W; chunk 2q + hh at position (2q + hh) ^ swz
     const int swz = (l31 >> 2) & 3;
@@ -453,46 +476,78 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(const GemmParams p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk = p.K / (BK * KSUB);
     dma(0, 0);
-    if (nk > 1) dma(1, 1);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // this wave's share of tile kt has landed (with three stages tile kt+1's four DMA instructions may still be in flight)
-        if (kt + 1 < nk) {
+    if (AHEAD > 1 && nk > 1) dma(1, 1);
+    // One K step on the compile-time stage CUR (the loop below is unrolled over the stages, so every LDS address of a step is a per-lane
+    // base register + an immediate: no vector ALU instruction sits between the MFMAs -- each one there cost MFMA issue slots, the
+    // scalar-base DMA form and this unrolling together took the steady-state loop from 0.80 to 0.87 of the MFMA peak).
+    auto step = [&](auto CUR, const int kt) {
+        constexpr int cur = decltype(CUR)::value;
+        constexpr int fill = cur + AHEAD >= STAGES ? cur + AHEAD - STAGES : cur + AHEAD;   // the stage read during step kt-1
+        // this wave's share of step kt has landed (with three stages step kt+1's four DMA instructions may still be in flight)
+        if (AHEAD > 1 && kt + 1 < nk) {
             if (TJ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... everyone's has, and nobody still reads the stage refilled next (the fragment reads of step kt-1 were waited for
         // before its MFMAs).  A raw s_barrier: __syncthreads() would add a vmcnt(0) fence and undo the counted wait.
-        __builtin_amdgcn_s_barrier();
+        if (!(ABLATE & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");   // the builtin is IntrNoMem: without this the LDS fragment reads below may be hoisted above it
         if (STAMP && kt == 0) t_first = wall_clock64();
-        const float* As = &smem[cur][0][0];
-        const float* Ws = &smem[cur][1][0];
-        const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
-        const int fill = cur == 0 ? STAGES - 1 : cur - 1;                          // the stage read during step kt-1
         // (pinning all eight fragment reads above the first MFMA with sched_barrier measured 7 % SLOWER: the compiler's own
         //  interleaving of the second four reads with the first sixteen MFMAs is the better schedule)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int po = q ? po1 : po0;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + ra + po);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + rb + po);
-            f32x4 b1 = b0;
-            if (TJ == 2) b1 = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
-            if (q == 0 && kt + STAGES - 1 < nk) dma(fill, kt + STAGES - 1);  // after the first fragment reads are on their way
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b0[jj], acc[0][0], 0, 0, 0);
-                if (TJ == 2) acc[0][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[jj], b1[jj], acc[0][TJ - 1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b0[jj], acc[1][0], 0, 0, 0);
-                if (TJ == 2) acc[1][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[jj], b1[jj], acc[1][TJ - 1], 0, 0, 0);
+        // order inside a step (the compiler's own choice in the rolled loop, pinned here because it moved the second four reads
+        // behind all sixteen MFMAs of the first half once the loop was unrolled): 4 reads | DMA | 14 MFMA | 4 reads | 2 MFMA | 16 MFMA
+        f32x4 fa0[2 * KSUB], fa1[2 * KSUB], fb0[2 * KSUB], fb1[2 * KSUB];
+        auto read_frags = [&](const int h) {       // h = 2 * ks + q: K columns 8h .. 8h+7 of the step
+            const float* As = &smem[cur][h >> 1][0][0];
+            const float* Ws = &smem[cur][h >> 1][1][0];
+            const int po = (h & 1) ? po1 : po0;
+            if (ABLATE & 2) {
+                const float v = (float)(lane + kt);
+                fa0[h] = f32x4{v, v + 1.f, v + 2.f, v + 3.f}; fa1[h] = fa0[h] + 1.f; fb0[h] = fa0[h] * 0.5f; fb1[h] = fb0[h] + 1.f;
+            } else {
+                fa0[h] = *reinterpret_cast<const f32x4*>(As + ra + po);
+                fa1[h] = *reinterpret_cast<const f32x4*>(As + ra + 32 * BK + po);
+                fb0[h] = *reinterpret_cast<const f32x4*>(Ws + rb + po);
+                fb1[h] = fb0[h];
+                if (TJ == 2) fb1[h] = *reinterpret_cast<const f32x4*>(Ws + rb + 32 * BK + po);
             }
+        };
+        auto mfma4 = [&](const int h, const int jj) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[h][jj], fb0[h][jj], acc[0][0], 0, 0, 0);
+            if (TJ == 2) acc[0][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[h][jj], fb1[h][jj], acc[0][TJ - 1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[h][jj], fb0[h][jj], acc[1][0], 0, 0, 0);
+            if (TJ == 2) acc[1][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[h][jj], fb1[h][jj], acc[1][TJ - 1], 0, 0, 0);
+        };
+        read_frags(0);
+        if (!(ABLATE & 1) && kt + AHEAD < nk) dma(fill, (ABLATE & 16) ? (kt & 1) : kt + AHEAD);  // after the first fragment reads are on their way
+#pragma unroll
+        for (int h = 0; h < 2 * KSUB; ++h) {
+            if (ABLATE & 8) {       // keep the fragments alive without multiplying
+                if (h + 1 < 2 * KSUB) read_frags(h + 1);
+                acc[0][0][h & 1] += fa0[h][0] + fa1[h][1] + fb0[h][2] + fb1[h][3];
+                continue;
+            }
+            mfma4(h, 0); mfma4(h, 1); mfma4(h, 2);
+            // jj = 3: two MFMAs, the next half's reads, the other two
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[h][3], fb0[h][3], acc[0][0], 0, 0, 0);
+            if (TJ == 2) acc[0][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[h][3], fb1[h][3], acc[0][TJ - 1], 0, 0, 0);
+            if (h + 1 < 2 * KSUB) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(h + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[h][3], fb0[h][3], acc[1][0], 0, 0, 0);
+            if (TJ == 2) acc[1][TJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[h][3], fb1[h][3], acc[1][TJ - 1], 0, 0, 0);
         }
-        cur = nxt;
+    };
+    for (int kt = 0; kt < nk; kt += STAGES) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+        if (STAGES == 3 && kt + 2 < nk) step(std::integral_constant<int, STAGES - 1>{}, kt + 2);
     }
     if (STAMP) t_loop = wall_clock64();
     gemm_epilogue_any<TJ>(p, acc, m0, n0, wr, wc, l31, hh);
@@ -540,7 +595,11 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
     int bk = 16;
     if (force_bk == 16 || force_bk == 32) bk = force_bk;
     static const bool no_dma = tuning_env("WT_GEMM_NO_DMA") != nullptr;  // A/B switch: register-staged kernel for every shape
-    if (!no_dma && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
+    // the LDS-DMA kernel addresses its operands with 32-bit byte offsets
+    const long long a_batches = (p.M + (long long)p.a_rows_per_batch - 1) / p.a_rows_per_batch;
+    const long long a_span = ((a_batches - 1) * (p.a_batch_stride > 0 ? p.a_batch_stride : 0) + (long long)p.a_rows_per_batch * p.lda + p.K) * 4;
+    const bool spans32 = a_span < (1ll << 32) && (long long)p.N * p.K * 4 < (1ll << 32) && p.a_batch_stride >= 0 && p.lda >= 0;
+    if (!no_dma && spans32 && force_bk == 0 && (p.K % 16) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0)
     {
         // 128x64 tiles when they balance the CUs better.  Two or three co-resident workgroups saturate a CU's MFMA pipes alike, so
         // a launch takes about ceil(tiles / 256 CUs) tile times; half-size tiles quantise that in half steps (5 % charged for their
@@ -549,7 +608,18 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
         const long long tiles64 = (long long)((p.N + 63) / 64) * nby;
         const double cost128 = (double)((tiles + 255) / 256), cost64 = 0.5 * 1.05 * (double)((tiles64 + 255) / 256);
         const bool bn64 = force_bn ? force_bn == 64 : cost64 < cost128;
-        if (p.dbg_stamps) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, 128>), dim3(tiles), dim3(256), 0, s, p);
+        static const int force_ksub = tuning_env("WT_GEMM_KSUB") ? atoi(tuning_env("WT_GEMM_KSUB")) : 0;
+        const bool ksub2 = force_ksub == 2 && (p.K % 32) == 0 && !bn64 && !p.dbg_stamps;
+        static const int ablate = tuning_env("WT_GEMM_ABLATE") ? atoi(tuning_env("WT_GEMM_ABLATE")) : 0;
+        if (ablate == 1) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 1>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ablate == 2) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 2>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ablate == 4) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 4>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ablate == 5) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 5>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ablate == 7) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 7>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ablate == 8) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 8>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ablate == 16) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 16>), dim3(tiles), dim3(256), 0, s, p);
+        else if (ksub2) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 2>), dim3(tiles), dim3(256), 0, s, p);
+        else if (p.dbg_stamps) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, 128>), dim3(tiles), dim3(256), 0, s, p);
         else if (bn64) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 64>), dim3((unsigned)tiles64), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128>), dim3(tiles), dim3(256), 0, s, p);
     }
