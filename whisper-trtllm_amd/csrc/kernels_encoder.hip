@@ -609,7 +609,10 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
         const double cost128 = (double)((tiles + 255) / 256), cost64 = 0.5 * 1.05 * (double)((tiles64 + 255) / 256);
         const bool bn64 = force_bn ? force_bn == 64 : cost64 < cost128;
         static const int force_ksub = tuning_env("WT_GEMM_KSUB") ? atoi(tuning_env("WT_GEMM_KSUB")) : 0;
-        const bool ksub2 = force_ksub == 2 && (p.K % 32) == 0 && !bn64 && !p.dbg_stamps;
+        // 128x128x32 steps on two 32 KiB stages (two workgroups per CU, half the barriers) for launches of many rounds: measured
+        // +6.5 % at 2256 tiles and +3.4 % at 3008 (medium.en q|k|v and fc1), equal at 752 / 1504 where the 3-per-CU form fills the chip
+        // in fewer rounds
+        const bool ksub2 = (force_ksub ? force_ksub == 2 : tiles >= 2048) && (p.K % 32) == 0 && !bn64 && !p.dbg_stamps;
         static const int ablate = tuning_env("WT_GEMM_ABLATE") ? atoi(tuning_env("WT_GEMM_ABLATE")) : 0;
         if (ablate == 1) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 1>), dim3(tiles), dim3(256), 0, s, p);
         else if (ablate == 2) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, 128, 1, 2>), dim3(tiles), dim3(256), 0, s, p);

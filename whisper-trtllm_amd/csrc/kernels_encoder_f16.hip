@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, HBK_ == 64 ? 2 : 3) void gemm_f16_kernel(const
     __half* smem = reinterpret_cast<__half*>(smem_raw);
     const __half* A = reinterpret_cast<const __half*>(p.A);
     const __half* W = reinterpret_cast<const __half*>(p.W);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -380,25 +380,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_dma_kernel(const GemmParams p
     // DMA map: wave w, pass j fills rows j*32 + w*8 .. +7; lane -> (row lane >> 3, chunk position lane & 7)
     const int r_local = lane >> 3;
     const int csrc = (lane & 7) ^ (((wave * 8 + r_local) >> 1) & 7);   // (row >> 1) & 7 with row = j*32 + w*8 + r_local
-    const __half* aptr[4];
-    const __half* wptr[4];
+    // 32-bit byte offsets + scalar bases, inline-asm requests: see gemm_f16_dma3_kernel
+    unsigned aoff[4], woff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = j * 32 + wave * 8 + r_local;
         const int m = min(m0 + row, p.M - 1);
         const int bb = m / p.a_rows_per_batch;
-        aptr[j] = A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8;
-        wptr[j] = W + (long long)min(n0 + row, p.N - 1) * p.K + csrc * 8;
+        aoff[j] = (unsigned)(((long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8) * 2);
+        woff[j] = (unsigned)(((long long)min(n0 + row, p.N - 1) * p.K + csrc * 8) * 2);
     }
-    typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)(&smem[0][0][0]) + (unsigned)wave * (8 * BK * 2);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 on the clobber list: it is written and consumed inside the one statement
     auto dma = [&](const int stage, const int kt) {
+        const unsigned st = lds_base + (unsigned)(stage * 2 * HBM_ * BK * 2);
+        const char* ab = reinterpret_cast<const char*>(A) + (long long)kt * (BK * 2);   // wave-uniform
+        const char* wb = reinterpret_cast<const char*>(W) + (long long)kt * (BK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * BK), (lptr_t)(&smem[stage][0][(j * 32 + wave * 8) * BK]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * BK), (lptr_t)(&smem[stage][1][(j * 32 + wave * 8) * BK]), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(st + (unsigned)(j * 32 * BK * 2)), "v"(aoff[j]), "s"(ab) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(st + (unsigned)((HBM_ + j * 32) * BK * 2)), "v"(woff[j]), "s"(wb) : "memory", "m0");
         }
     };
+#pragma clang diagnostic pop
     // fragment reads (16x16x32: lane -> row l15 of the 16-row tile, 16-byte k-chunk kq + 4 s): tile i of A = rows wr*64 + 16 i + l15;
     // (row >> 1) & 7 == (l15 >> 1) for every tile (16 i and wr*64 are multiples of 16)
     const int swz = (l15 >> 1) & 7;
@@ -665,8 +673,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
     // W: 16 instructions (pass j < 2).  lane -> (row lane >> 3, chunk position lane & 7); source chunk = pos ^ ((row >> 1) & 7)
     const int r_local = lane >> 3;
     const int csrc = (lane & 7) ^ (((wave * 8 + r_local) >> 1) & 7);
-    const __half* aptr[4];
-    const __half* wptr[2];
+    // per-lane BYTE offsets of the six source rows (32 bits: launch_gemm_f16 checks that the operands span < 4 GiB); the K step's
+    // column offset is wave-uniform and goes into the scalar base, the LDS destination is scalar too: a request is
+    // `s_mov m0 | global_load_lds v_off, s[base]` -- no vector ALU work between the MFMAs (from the builtin hipcc selects the 64-bit
+    // vector-address form and spends a v_lshl_add_u64 per request; every such instruction costs MFMA issue slots)
+    unsigned aoff[4], woff[2];
     auto set_tile_ptrs = [&](const int i) {
         int m0, n0;
         tile_origin(i, m0, n0);
@@ -674,22 +685,29 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma3_kernel(const GemmParams 
         for (int j = 0; j < 4; ++j) {
             const int m = min(m0 + j * 64 + wave * 8 + r_local, p.M - 1);
             const int bb = m / p.a_rows_per_batch;
-            aptr[j] = A + (long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8;
+            aoff[j] = (unsigned)(((long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8) * 2);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wptr[j] = W + (long long)min(n0 + j * 64 + wave * 8 + r_local, p.N - 1) * p.K + csrc * 8;
+        for (int j = 0; j < 2; ++j) woff[j] = (unsigned)(((long long)min(n0 + j * 64 + wave * 8 + r_local, p.N - 1) * p.K + csrc * 8) * 2);
     };
-    typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem + (unsigned)wave * (8 * H3_BK * 2);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 on the clobber list: it is written and consumed inside the one statement
     auto dma = [&](const int stage, const int kt) {
-        _Float16* st = smem + stage * H3_STAGE;
+        const unsigned st = lds_base + (unsigned)(stage * H3_STAGE * 2);
+        const char* ab = reinterpret_cast<const char*>(A) + (long long)kt * (H3_BK * 2);   // wave-uniform
+        const char* wb = reinterpret_cast<const char*>(W) + (long long)kt * (H3_BK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(aptr[j] + kt * H3_BK), (lptr_t)(st + (j * 64 + wave * 8) * H3_BK), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(st + (unsigned)(j * 64 * H3_BK * 2)), "v"(aoff[j]), "s"(ab) : "memory", "m0");
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[j] + kt * H3_BK), (lptr_t)(st + H3_BM * H3_BK + (j * 64 + wave * 8) * H3_BK), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(st + (unsigned)((H3_BM + j * 64) * H3_BK * 2)), "v"(woff[j]), "s"(wb) : "memory", "m0");
     };
+#pragma clang diagnostic pop
     const int swz = (l15 >> 1) & 7;
     const int ra = (wr * 64 + l15) * H3_BK, rb = H3_BM * H3_BK + (wc * 64 + l15) * H3_BK;
     const int po0 = ((kq + 0) ^ swz) * 8, po1 = ((kq + 4) ^ swz) * 8;
@@ -1182,7 +1200,7 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
         hipLaunchKernelGGL(gemm_f16_dma4_kernel<true>, grid4, dim3(512), H4_SMEM, s, p);
         return hipGetLastError();
     }
-    if (dma_ok && use3) {
+    if (dma_ok && use3 && span32) {
         static PerDeviceFlag attr3;
         if (!attr3.get()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_dma3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_SMEM);
@@ -1196,7 +1214,7 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
         else hipLaunchKernelGGL(gemm_f16_dma3_kernel<false>, grid3, dim3(512), H3_SMEM, s, p);
         return hipGetLastError();
     }
-    if (dma_ok) {
+    if (dma_ok && span32) {
         if (out_half) hipLaunchKernelGGL(gemm_f16_dma_kernel<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(gemm_f16_dma_kernel<false>, grid, dim3(256), 0, s, p);
         return hipGetLastError();
