@@ -173,6 +173,27 @@ def test_gemm_identity_asymmetric(lib):
     np.testing.assert_allclose(C.cpu().numpy(), W.t().numpy(), rtol=1e-6, atol=1e-6)
 
 
+def test_gemm_gelu_epilogue_accuracy(lib):
+    """The encoder's GELU (csrc/kernels_encoder.hip: gelu_erf, a branch-free erf fitted by tools/fit_gelu.py) measured alone: A = I makes
+    the product exact, so C = gelu(W^T) element for element.  Against the float64 erf form: within 6e-7 max(|x|, 1) -- one float32 ulp
+    of the result -- on a grid over [-12, 12] plus the values where the polynomial's error peaks, zero, and +-large."""
+    n = 256
+    x = torch.linspace(-12.0, 12.0, n * n - 8, dtype=torch.float64)
+    x = torch.cat([x, torch.tensor([0.0, -0.0, 4.341, -4.341, 5.5437, -5.5437, 30.0, -30.0], dtype=torch.float64)]).float()
+    W = x.reshape(n, n)
+    Ad, Wd = torch.eye(n).cuda(), W.cuda()
+    C = torch.empty(n, n, device="cuda")
+    assert lib.wt_dbg_gemm(P(Ad), n, P(Wd), None, None, P(C), n, n, n, 1, _stream()) == 0
+    torch.cuda.synchronize()
+    xd = W.t().double()
+    want = 0.5 * xd * (1.0 + torch.erf(xd / 2.0 ** 0.5))
+    err = (C.cpu().double() - want).abs() / xd.abs().clamp(min=1.0)
+    assert err.max().item() < 6e-7, (err.max().item(), xd.flatten()[err.argmax()].item())
+    got = C.cpu()
+    assert got[W.t() == 0].abs().max().item() == 0.0 and torch.isfinite(got).all()
+    assert got[W.t() == 30.0].item() == 30.0 and got[W.t() == -30.0].abs().item() < 1e-30
+
+
 @pytest.mark.parametrize("rows,d", [(7, 128), (1500, 384), (33, 1024), (5, 192), (4, 768)])
 def test_layernorm(lib, rows, d):
     x, w, b = _rand(rows, d, seed=5, scale=3.0) + 0.7, _rand(d, seed=6), _rand(d, seed=7)

@@ -12,18 +12,8 @@ namespace wt {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside the fp16 path's tolerance): one rcp + one exp + 6 FMAs
-// instead of erff()'s ~40 instructions -- the GELU epilogue of a K=1024 fp16 tile otherwise costs as much as its main loop
-__device__ __forceinline__ float gelu_erf_h(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erf_abs = 1.0f - poly * t * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
+// GELU of the fp16 epilogues: the branch-free erf form shared with the fp32 encoder (wt_common.h: gelu_erf; was A&S 7.1.26 with an rcp + exp)
+__device__ __forceinline__ float gelu_erf_h(float x) { return gelu_erf(x); }
 
 // ------------------------------------------------------------------------------------------------ fp32 -> fp16 helpers
 // mel [B][C][F] fp32 -> melT [B][F+2][C] fp16 (row = time+1; rows 0 / F+1 zero) : conv1 as implicit GEMM, K = 3C
@@ -361,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_dma_kernel(const GemmParams p
     __shared__ __attribute__((aligned(1024))) _Float16 smem[2][2][HBM_ * BK];  // [stage][A | W][row * 64 + pos * 8]
     const __half* A = reinterpret_cast<const __half*>(p.A);
     const __half* W = reinterpret_cast<const __half*>(p.W);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
 

@@ -200,4 +200,24 @@ hipError_t launch_copy_cache_rows(const float* src, float* dst, int LH, int src_
                                   hipStream_t s);
 hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s);
 
+// GELU (erf form) of the encoder epilogues.  erff() is ~38 vector ALU instructions in two divergent branches, executed beside the other
+// workgroups' MFMAs: 10 % of a small.en fc1 launch, 4 % of medium.en's.  Branch-free form: erf(|x| / sqrt 2) = 1 - 2^Q(|x|), Q of degree 8
+// without constant term (coefficients and error check: tools/fit_gelu.py), and
+//   gelu(x) = x - h for x >= 0,  h for x < 0,  h = 0.5 x 2^Q(|x|)       (no 1 + erf cancellation in the negative tail)
+// 13 instructions + one v_exp_f32.  |gelu_erf - exact| <= 5.1e-7 on [-12, 12] in float32 arithmetic, <= 1.3e-7 max(|x|, 1): one ulp of the
+// result, the size of the rounding of x - h itself.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float t = fabsf(x);   // no clamp: beyond the fitted range Q(t) t keeps falling monotonically to -inf (checked in fit_gelu.py), 2^Q -> 0
+    float q = -2.835055965988431e-06f;
+    q = fmaf(q, t, 3.937911969842389e-05f);
+    q = fmaf(q, t, -0.00018618583271745592f);
+    q = fmaf(q, t, -0.00013692546053789556f);
+    q = fmaf(q, t, 0.007063408847898245f);
+    q = fmaf(q, t, -0.05249617248773575f);
+    q = fmaf(q, t, -0.4592081904411316f);
+    q = fmaf(q, t, -1.1511051654815674f);
+    const float h = (0.5f * x) * __builtin_amdgcn_exp2f(q * t);
+    return x >= 0.f ? x - h : h;
+}
+
 }  // namespace wt
