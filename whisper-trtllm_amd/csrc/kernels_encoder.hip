@@ -696,15 +696,16 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
     FA_GLOAD(0);
     FA_LSTORE(0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    // One 64-key tile; LAST = the final (possibly ragged) one.  Peeled because hipcc if-converts the ragged-tile test into 32 compares +
+    // 32 selects executed on EVERY tile -- a fifth of the loop's vector ALU work, which competes with the MFMAs for issue.
+    auto tile = [&](auto LAST_T, const int t) {
+        constexpr bool LAST = decltype(LAST_T)::value;
         const int cur = t & 1, kv0 = t * FA_BKV;
-        if (t + 1 < ntiles) FA_GLOAD(kv0 + FA_BKV);
+        if (!LAST) FA_GLOAD(kv0 + FA_BKV);
         const float* Ks = smem + cur * (2 * FA_BKV * FA_LD);
         const float* Vs = Ks + FA_BKV * FA_LD;
 
         f32x16 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
         const float* kp = Ks + l31 * FA_LD + 4 * hh;
         // K fragments are read one 8-wide k-group ahead of the MFMAs that use them
         f32x4 kf0[8], kf1[8];
@@ -720,8 +721,14 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
                 kf1[q + 2] = *reinterpret_cast<const f32x4*>(kp + 32 * FA_LD + 8 * (q + 2));
             }
             const f32x4 k0 = kf0[q], k1 = kf1[q], qq = qf[q];
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[0], qq[0], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[0], qq[0], s1, 0, 0, 0);
+            if (q == 0) {   // the tile's first products start from the inline constant 0 (no 32 v_mov per tile to clear the score registers)
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[0], qq[0], zero16, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[0], qq[0], zero16, 0, 0, 0);
+            } else {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[0], qq[0], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[0], qq[0], s1, 0, 0, 0);
+            }
             s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[1], qq[1], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[1], qq[1], s1, 0, 0, 0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[2], qq[2], s0, 0, 0, 0);
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
             s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[3], qq[3], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[3], qq[3], s1, 0, 0, 0);
         }
-        if (kv0 + FA_BKV > S) {  // ragged last tile: keys >= S get probability 0
+        if (LAST && kv0 + FA_BKV > S) {  // ragged last tile: keys >= S get probability 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -787,9 +794,11 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[i], s1[4 * g + i], o1, 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) FA_LSTORE(cur ^ 1);
+        if (!LAST) FA_LSTORE(cur ^ 1);
         __syncthreads();
-    }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{}, t);
+    tile(std::true_type{}, ntiles - 1);
 #undef FA_GLOAD
 #undef FA_LSTORE
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
