@@ -173,6 +173,29 @@ def test_gemm_identity_asymmetric(lib):
     np.testing.assert_allclose(C.cpu().numpy(), W.t().numpy(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_gemm_operand_span_over_4gib_takes_the_64bit_path(lib, half):
+    """The LDS-DMA GEMMs address their operands with 32-bit byte offsets from a scalar base; the launchers must send an operand that spans
+    4 GiB or more to the register-staged kernels (64-bit addresses).  A with a row stride of 512 MiB and 9 rows spans 4.5 GiB (only K
+    elements per row are ever read); a wrapped offset would stay inside the allocation and read row (m mod 8) instead of row m."""
+    M, N, K = 9, 128, 64
+    lda = (1 << 27) if not half else (1 << 28)                    # elements: 512 MiB per row either way
+    dt = torch.float16 if half else torch.float32
+    big = torch.empty(M * lda, dtype=dt, device="cuda")
+    rows = _rand(M, K, seed=21).to(dt)
+    big.view(M, lda)[:, :K] = rows.cuda()
+    W = _rand(N, K, seed=22, scale=K ** -0.5).to(dt)
+    Wd, C = W.cuda(), torch.empty(M, N, device="cuda")
+    if half:
+        assert lib.wt_dbg_gemm_f16(P(big), lda, P(Wd), None, None, P(C), M, N, K, 0, 0, _stream()) == 0
+    else:
+        assert lib.wt_dbg_gemm(P(big), lda, P(Wd), None, None, P(C), M, N, K, 0, _stream()) == 0
+    torch.cuda.synchronize()
+    ref = rows.double() @ W.double().t()
+    assert (C.cpu().double() - ref).abs().max().item() < (2e-3 if half else 2e-5)
+    del big
+
+
 def test_gemm_gelu_epilogue_accuracy(lib):
     """The encoder's GELU (csrc/kernels_encoder.hip: gelu_erf, a branch-free erf fitted by tools/fit_gelu.py) measured alone: A = I makes
     the product exact, so C = gelu(W^T) element for element.  Against the float64 erf form: within 6e-7 max(|x|, 1) -- one float32 ulp
