@@ -625,11 +625,14 @@ __device__ __forceinline__ float row8_allreduce_sum(float v) {   // sum over eac
 // PIPE: the U keys a stream takes per iteration are handled as two half-tiles with their own registers; the loads of one half are in
 // flight while the other is consumed (the same number of loads in flight as the plain form, but the exp / FMA work of a half-tile --
 // a fifth of an iteration with fp16 caches, a tenth with fp32 -- no longer sits between one tile's arrival and the next request).
-template <int U, bool NT, bool KVH, bool PIPE = false, bool ALIVE = false>
-__global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
+// NTHR = 512: eight waves per block = twice the streams, half the dependent load -> consume round trips per stream and twice the bytes
+// in flight per CU (the kernel is bound by round trips x bytes in flight, not by the HBM rate: it takes 17.1 us with a layer's K/V
+// resident in the Infinity Cache and 17.8 from HBM).
+template <int U, bool NT, bool KVH, bool PIPE = false, bool ALIVE = false, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
     constexpr int LPK = KVH ? 8 : 16;          // lanes per key
     constexpr int DPL = HEAD_DIM / LPK;        // head dims per lane: 8 or 4 (16 bytes of K or V either way)
-    constexpr int NSTR = 256 / LPK;            // online-softmax streams per block
+    constexpr int NSTR = NTHR / LPK;           // online-softmax streams per block
     constexpr int KSZ = KVH ? 2 : 4;
     __shared__ float sm_o[NSTR][HEAD_DIM];
     __shared__ float sm_m[NSTR], sm_l[NSTR];
@@ -640,6 +643,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     const int chunk = (len + p.n_split - 1) / p.n_split;
     const int s_begin = split * chunk, s_end = min(len, s_begin + chunk);
     const int d = p.H * HEAD_DIM;
+    // streams in use: all of them, except that an eight-wave block over a short key range (self-attention early in a transcript) works
+    // as a four-wave one -- waves 4-7 leave at once (a finished wave does not hold a barrier), and the merge below walks half as many
+    // partials: at 32 keys the full eight-wave form measured 3.8 us against 3.3
+    static_assert(NTHR == 256 || !KVH, "the wide blocks exist for fp32 caches only (16 lanes per key)");
+    const int nkeys = s_end - s_begin;
+    const int nstr = NTHR == 256 ? NSTR : nkeys < 128 ? 16 : (nkeys < 384 || NTHR == 512) ? 32 : NSTR;
+    if (NTHR != 256 && sid >= nstr) return;   // wave-uniform (LPK divides 64)
 
     const char* kb = reinterpret_cast<const char*>(p.kcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
     const char* vb = reinterpret_cast<const char*>(p.vcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     auto load_tile = [&](f4v (&kk)[U], f4v (&vv)[U], const int s0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t key = (size_t)min(s0 + NSTR * u, s_end - 1) * (HEAD_DIM * KSZ);
+            const size_t key = (size_t)min(s0 + nstr * u, s_end - 1) * (HEAD_DIM * KSZ);
             if (NT) {  // K/V are read exactly once per step: non-temporal loads keep them from displacing weights in L2
                 kk[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(kb + key));
                 vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vb + key));
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     auto load_half = [&](const int h, const int s0) {   // half-tile h = registers [h * UH, (h + 1) * UH); unconditional clamped loads
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
-            const size_t key = (size_t)min(s0 + NSTR * u, s_end - 1) * (HEAD_DIM * KSZ);
+            const size_t key = (size_t)min(s0 + nstr * u, s_end - 1) * (HEAD_DIM * KSZ);
             if (NT) {
                 kk[h * UH + u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(kb + key));
                 vv[h * UH + u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(vb + key));
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     if constexpr (PIPE) {
         if (s_begin < s_end) {   // block-uniform; clamping keeps every address inside this block's keys
             load_half(0, s_first);
-            load_half(1, s_first + NSTR * UH);
+            load_half(1, s_first + nstr * UH);
         }
     } else {
         if (s_first < s_end) load_tile(kk, vv, s_first);
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
 #pragma unroll
             for (int i = DPL - 2; i >= 0; --i) dot = fmaf(q[i], kf[i], dot);
             sc[u] = KVH ? row8_allreduce_sum(dot) : row16_allreduce_sum(dot);
-            if (s0 + NSTR * u >= s_end) sc[u] = -INFINITY;
+            if (s0 + nstr * u >= s_end) sc[u] = -INFINITY;
             mx = fmaxf(mx, sc[u]);
         }
         // plain form: s0 < s_end, so u = 0 is a real key and mx is finite.  PIPE consumes branch-free (a skipped consumer would make
@@ -783,9 +793,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
         m = mx;
     };
     if constexpr (PIPE) {
-        const int stride = NSTR * U;
+        const int stride = nstr * U;
         const int n_it = (s_end - s_begin + stride - 1) / stride;   // block-uniform; a stream's own keys end up to one iteration earlier
-        int sA = s_first, sB = s_first + NSTR * UH;
+        int sA = s_first, sB = s_first + nstr * UH;
         // every load of the prologue (query, LayerNorm operands) has landed before the loop: the waitcnt pass merges the loop-entry
         // state into every iteration, so a register still pending at entry costs a near-full drain per iteration (seen in the ISA
         // as vmcnt(1) / vmcnt(0) in front of the first FMA that reads q).  vmcnt(0), lgkmcnt / expcnt untouched:
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        for (int s0 = s_first; s0 < s_end; s0 += NSTR * U) {  // (a register double buffer of WHOLE tiles measured 0.5-1 us SLOWER per launch)
+        for (int s0 = s_first; s0 < s_end; s0 += nstr * U) {  // (a register double buffer of WHOLE tiles measured 0.5-1 us SLOWER per launch)
             if (s0 != s_first) load_tile(kk, vv, s0);
             consume(0, s0);
         }
@@ -821,11 +831,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const DecAttnParams p) {
     if (wave != 0) return;  // wave-uniform: only wave 0 publishes / merges
     float M = sm_m[0];
 #pragma unroll
-    for (int i = 1; i < NSTR; ++i) M = fmaxf(M, sm_m[i]);
+    for (int i = 1; i < NSTR; ++i)
+        if (NTHR == 256 || i < nstr) M = fmaxf(M, sm_m[i]);
     float o = 0.f, L = 0.f;
     if (M > -INFINITY) {
 #pragma unroll
         for (int i = 0; i < NSTR; ++i) {
+            if (NTHR != 256 && i >= nstr) break;
             const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
             o = fmaf(w, sm_o[i][lane], o);
             L = fmaf(w, sm_l[i], L);
@@ -893,6 +905,19 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     // 13.35 -> 12.84 (two splits) / 15.28 -> 13.49 (one); fp32 caches 19.87 vs 19.98 (no gain: a tenth of an iteration is arithmetic
     // there, a fifth with fp16 caches) -- so fp16 caches only.  A/B: WT_ATTN_PIPE=0|1 forces it off / on for both.
     static const int pipe = tuning_env("WT_ATTN_PIPE") ? atoi(tuning_env("WT_ATTN_PIPE")) : -1;
+    // fp32 caches: eight-wave blocks (measured per launch, 256 -> 512 threads: cross-attention, two splits 19.5 -> 18.8 us, one split
+    // (batch 16) 23.9 -> 19.9; self-attention at 224 / 447 keys 6.6 -> 5.7 / 9.4 -> 8.3; below 128 keys the block works as four waves).
+    // A/B: WT_ATTN_THREADS=256|512.
+    static const int threads = tuning_env("WT_ATTN_THREADS") ? atoi(tuning_env("WT_ATTN_THREADS")) : 512;
+    // (sixteen-wave blocks measured SLOWER than eight: cross-attention 19.2 -> 20.6 us, self-attention at 224 keys 5.9 -> 6.4)
+    // (and four keys per stream and iteration stay best in the eight-wave form: U = 2 / 4 / 8 -> 19.9 / 19.8 / 20.1 us cross-attention,
+    //  6.3 / 5.8 / 6.0 us self-attention at 224 keys)
+    if (threads == 512 && !p.kv_half && pipe != 1) {
+        if (p.alive && nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, true, 512>), grid, dim3(512), 0, s, p);
+        else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, false, 512>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((dec_attn_kernel<4, false, false, false, false, 512>), grid, dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
     if (p.alive) {   // the skip-finished-rows step graph (non-temporal streaming forms only; others fall through to the plain kernels)
         if (p.kv_half && nt && pipe != 0) { hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true, true>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
         if (!p.kv_half && nt && pipe != 1) { hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, true>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
