@@ -217,7 +217,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
     q = fmaf(q, t, -0.4592081904411316f);
     q = fmaf(q, t, -1.1511051654815674f);
     const float h = (0.5f * x) * __builtin_amdgcn_exp2f(q * t);
-    return x >= 0.f ? x - h : h;
+    // (fmaxf: gelu(x) >= x / 2 for x >= 0, so the max is an identity for finite x; for x = +inf, where h = inf * 0 = NaN, it returns +inf
+    //  like the erf form.  x = -inf gives NaN in both forms, NaN stays NaN.)
+    return x >= 0.f ? fmaxf(x - h, 0.5f * x) : h;
 }
 
 }  // namespace wt
