@@ -645,7 +645,19 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
                                                           int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * FA_BQ;
+    // XCD-aware order (1-D grid; workgroup L runs on XCD L % 8): the query blocks of one (utterance, head) go to ONE XCD, back to back, so
+    // the head's K and V (768 KB at S = 1500) are fetched into one L2 instead of eight.  With the plain (x, y, z) grid the 12 query blocks
+    // of a head were dealt round-robin over the XCDs: 847 MB fetched per launch for 147 MB of q|k|v (PMC, profiles/r03b_pmc_fetch_...).
+    int b, h, q0;
+    {
+        // XCD x owns a contiguous chunk of the head-major list of (head, query block) pairs (the chunking of gemm_f32_kernel: a bijection
+        // for any total); a head that straddles a chunk boundary is fetched by two XCDs
+        const int nqb = (S + FA_BQ - 1) / FA_BQ, total = (int)gridDim.x;
+        const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int bh = v / nqb;
+        b = bh / H; h = bh % H; q0 = (v - bh * nqb) * FA_BQ;
+    }
     const int d = H * HEAD_DIM, ld = 3 * d;
     const float* base = qkv + (size_t)b * S * ld + h * HEAD_DIM;
 
@@ -822,7 +834,7 @@ hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, 
         if (e != hipSuccess) return e;
         attr_set.set();
     }
-    dim3 grid((S + FA_BQ - 1) / FA_BQ, H, B);
+    dim3 grid(((S + FA_BQ - 1) / FA_BQ) * H * B);
     hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(256), FA_SMEM, s, qkv, ctx, S, H);
     return hipGetLastError();
 }

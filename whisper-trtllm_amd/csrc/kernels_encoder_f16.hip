@@ -1238,7 +1238,14 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char ha_raw[];
     _Float16* smem = reinterpret_cast<_Float16*>(ha_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * HA_BQ;
+    int b, h, q0;
+    {   // XCD-chunked head-major order, as in enc_attn_kernel: a head's K / V land in one L2 instead of eight
+        const int nqb = (S + HA_BQ - 1) / HA_BQ, total = (int)gridDim.x;
+        const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int bh = v / nqb;
+        b = bh / H; h = bh % H; q0 = (v - bh * nqb) * HA_BQ;
+    }
     const int d = H * HEAD_DIM, ld = 3 * d;
     const _Float16* base = reinterpret_cast<const _Float16*>(qkv) + (size_t)b * S * ld + h * HEAD_DIM;
 
@@ -1365,7 +1372,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
 }
 
 hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S, int H, hipStream_t s) {
-    dim3 grid((S + HA_BQ - 1) / HA_BQ, H, B);
+    dim3 grid(((S + HA_BQ - 1) / HA_BQ) * H * B);
     hipLaunchKernelGGL(enc_attn_f16_kernel, grid, dim3(256), HA_SMEM, s, (const __half*)qkv, (__half*)ctx, S, H);
     return hipGetLastError();
 }
