@@ -57,7 +57,12 @@ def test_gemm(lib, M, N, K, act, use_res):
     # every epilogue kind wt_dbg_gemm can reach (plain, GELU, residual in place)
     (4000, 3200, 48, 0, False), (4100, 3210, 64, 1, False), (5000, 2600, 256, 0, True), (12000, 1100, 64, 0, True),
     # (one-round launches of 752 tiles with one and two K-steps per tile: fewer K-steps than pipeline stages)
-    (12000, 1000, 16, 0, False), (11900, 1024, 32, 1, False)])
+    (12000, 1000, 16, 0, False), (11900, 1024, 32, 1, False),
+    # >= 2048 tiles with K % 32 == 0: the two-stage 128x128x32 form (one, two, three and five K steps: fewer than, as many as and more than
+    # its pipeline stages; GELU, residual in place, ragged last row tile)
+    (12000, 3072, 32, 0, False), (12000, 3072, 64, 1, False), (11990, 3072, 96, 0, True), (8200, 4096, 160, 1, False),
+    # the same launches with K % 32 == 16: they must take the three-stage 128x128x16 form
+    (12000, 3072, 48, 0, True)])
 def test_gemm_many_tiles(lib, M, N, K, act, use_res):
     A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
     R = _rand(M, N, seed=4) if use_res else None
