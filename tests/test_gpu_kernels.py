@@ -300,7 +300,11 @@ def test_skinny(lib, B, N, K, xmode, act, use_res):
 
 
 @pytest.mark.parametrize("B,H,cap,length,n_split", [(1, 2, 40, 1, 1), (3, 2, 40, 17, 2), (2, 6, 1500, 1500, 8), (8, 2, 448, 447, 3),
-                                                    (1, 1, 96, 96, 16), (2, 3, 160, 5, 4), (1, 2, 64, 63, 1)])
+                                                    (1, 1, 96, 96, 16), (2, 3, 160, 5, 4), (1, 2, 64, 63, 1),
+                                                    # around the eight-wave kernel's stream-count switch (128 keys per split): 16 streams below,
+                                                    # 32 from there on; fewer keys than streams; one key per stream
+                                                    (2, 2, 448, 127, 1), (2, 2, 448, 128, 1), (2, 2, 448, 129, 1), (3, 2, 448, 255, 2),
+                                                    (3, 2, 448, 256, 2), (3, 2, 448, 257, 2), (1, 4, 448, 31, 1), (1, 4, 448, 32, 1), (2, 2, 448, 33, 2)])
 def test_decode_attention(lib, B, H, cap, length, n_split):
     d = 64 * H
     q = _rand(B, d, seed=15) * 0.5
