@@ -829,20 +829,25 @@ __global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
     }
     __syncthreads();
     if (wave != 0) return;  // wave-uniform: only wave 0 publishes / merges
-    float M = sm_m[0];
+    // merge of the streams' partials by wave 0, with a COMPILE-TIME trip count in either case (a run-time bound keeps hipcc from issuing
+    // the LDS reads of all partials ahead of the first exp: the loop then pays one LDS round trip per stream)
+    float M, o = 0.f, L = 0.f;
+    auto merge = [&](auto COUNT) {
+        constexpr int n = decltype(COUNT)::value;
+        M = sm_m[0];
 #pragma unroll
-    for (int i = 1; i < NSTR; ++i)
-        if (NTHR == 256 || i < nstr) M = fmaxf(M, sm_m[i]);
-    float o = 0.f, L = 0.f;
-    if (M > -INFINITY) {
+        for (int i = 1; i < n; ++i) M = fmaxf(M, sm_m[i]);
+        if (M > -INFINITY) {
 #pragma unroll
-        for (int i = 0; i < NSTR; ++i) {
-            if (NTHR != 256 && i >= nstr) break;
-            const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
-            o = fmaf(w, sm_o[i][lane], o);
-            L = fmaf(w, sm_l[i], L);
+            for (int i = 0; i < n; ++i) {
+                const float w = __expf(sm_m[i] - M);  // streams with no key have m = -inf -> weight 0
+                o = fmaf(w, sm_o[i][lane], o);
+                L = fmaf(w, sm_l[i], L);
+            }
         }
-    }
+    };
+    if (NTHR == 256 || nstr == NSTR) merge(std::integral_constant<int, NSTR>{});
+    else merge(std::integral_constant<int, 16>{});
     float* outp = p.out + (size_t)b * d + h * HEAD_DIM;
     if (p.n_split == 1) {
         outp[lane] = o / L;
