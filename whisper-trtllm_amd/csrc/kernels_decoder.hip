@@ -646,9 +646,9 @@ __global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
     // streams in use: all of them, except that an eight-wave block over a short key range (self-attention early in a transcript) works
     // as a four-wave one -- waves 4-7 leave at once (a finished wave does not hold a barrier), and the merge below walks half as many
     // partials: at 32 keys the full eight-wave form measured 3.8 us against 3.3
-    static_assert(NTHR == 256 || !KVH, "the wide blocks exist for fp32 caches only (16 lanes per key)");
+    static_assert(NTHR == 256 || NTHR == 512, "four- or eight-wave blocks");
     const int nkeys = s_end - s_begin;
-    const int nstr = NTHR == 256 ? NSTR : nkeys < 128 ? 16 : (nkeys < 384 || NTHR == 512) ? 32 : NSTR;
+    const int nstr = (NTHR == 256 || nkeys >= 128) ? NSTR : NSTR / 2;
     if (NTHR != 256 && sid >= nstr) return;   // wave-uniform (LPK divides 64)
 
     const char* kb = reinterpret_cast<const char*>(p.kcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
         }
     };
     if (NTHR == 256 || nstr == NSTR) merge(std::integral_constant<int, NSTR>{});
-    else merge(std::integral_constant<int, 16>{});
+    else merge(std::integral_constant<int, NSTR / 2>{});
     float* outp = p.out + (size_t)b * d + h * HEAD_DIM;
     if (p.n_split == 1) {
         outp[lane] = o / L;
@@ -923,6 +923,8 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
         else hipLaunchKernelGGL((dec_attn_kernel<4, false, false, false, false, 512>), grid, dim3(512), 0, s, p);
         return hipGetLastError();
     }
+    // (fp16 caches stay on four-wave blocks -- they already are 32 streams, 8 lanes per key: eight waves = 64 streams measured 18.65 vs 18.6 us
+    //  at batch 16 and 13.1 vs 13.1 at batch 8 with two splits)
     if (p.alive) {   // the skip-finished-rows step graph (non-temporal streaming forms only; others fall through to the plain kernels)
         if (p.kv_half && nt && pipe != 0) { hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true, true>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
         if (!p.kv_half && nt && pipe != 1) { hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, true>), grid, dim3(256), 0, s, p); return hipGetLastError(); }
