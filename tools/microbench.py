@@ -137,6 +137,22 @@ def bench_skinny_floor(B=8):
         print(f"skinny N={N} K={K} xmode={xmode} rotating {n_rot}: {us:7.2f} us")
 
 
+def bench_skinny_resident(B=8):
+    """How fast is a decode GEMV whose weights wait in the Infinity Cache (256 MB) but NOT in the XCD's L2 (4 MB)?  The same launch over
+    n_rot rotating weight sets: 1 set = L2 + Infinity Cache resident, 4-12 sets = Infinity Cache only (each XCD's share of every set is
+    evicted from its L2 between uses), 24 sets = from HBM (what the decode step sees today)."""
+    for (N, K, xmode) in ((4096, 1024, 5), (1024, 4096, 4), (3072, 1024, 5), (1024, 1024, 4)):
+        for n_rot in (1, 2, 4, 8, 12, 24, 48):
+            if n_rot * N * K * 4 > 1.2e9:
+                continue
+            W = torch.randn(n_rot, N, K, device="cuda") * 0.02
+            X = torch.randn(B, K, device="cuda")
+            g, be, bias = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(N, device="cuda")
+            Y = torch.empty(B, N, device="cuda")
+            us = timeit(lambda i: lib.wt_dbg_skinny(P(X), P(g), P(be), P(W[i % n_rot]), P(bias), None, P(Y), B, N, K, xmode, 0, 1.0, ST()), 48)
+            print(f"skinny N={N} K={K} xmode={xmode} rotating {n_rot:2d} sets ({n_rot * N * K * 4 / 1e6:6.1f} MB): {us:7.2f} us")
+
+
 def bench_gemm(M=12000):
     for (N, K, act) in ((3072, 1024, 0), (1024, 1024, 0), (4096, 1024, 1), (1024, 4096, 0), (2048, 1024, 0)):
         A = torch.randn(M, K, device="cuda")

@@ -378,6 +378,9 @@ static int enc_reserve(wt_engine* e, int B, hipStream_t s) {
     // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
     HIPCHK(hipMemsetAsync(e->melT, 0, ((size_t)B * (Fr + 2) * e->C + 4 * e->C) * 4, s));
     HIPCHK(hipMemsetAsync(e->c1, 0, ((size_t)B * (Fr + 2) * d + 4 * d) * 4, s));
+    // Growth is rare.  The ABI takes a stream per call: finish the clears before returning, so that a following call on this handle
+    // from a DIFFERENT stream cannot overtake them (allowed while other threads capture: thread-local capture mode)
+    HIPCHK(hipStreamSynchronize(s));
     e->enc_cap = B;
     return WT_OK;
 }
@@ -535,6 +538,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s) {
     if (!e->own_stream) {
         HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     }
+    HIPCHK(hipStreamSynchronize(s));   // as in enc_reserve: the ticket clear above is ordered before any later call on any stream
     e->dec_cap = B;
     e->dec_maxlen_cap = cap_len;
     return WT_OK;
