@@ -39,11 +39,11 @@ def log(*a):
 
 
 def under_rocprof() -> bool:
-    """rocprofv3 preloads its tool library into the benchmarked process.  Its kernel-trace interception of hipGraph replays is not safe
-    with SEVERAL host threads replaying graphs at once (a 4-worker run under `rocprofv3 --kernel-trace` segfaults inside the runtime;
-    the same run without the profiler is what the test suite and this benchmark do all the time), so the multi-worker legs are skipped
-    when the tool is loaded -- the kernels they launch are the ones the single-worker legs profile."""
-    return "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or any(k.startswith("ROCPROF_") for k in os.environ)
+    """rocprofv3's tool library is loaded into this process (whisper_trtllm_amd.runtime.under_rocprof: WhisperPipeline clamps itself to one
+    worker then -- a 4-worker run under `rocprofv3 --kernel-trace` aborted in round 3, DESIGN.md "The four-worker abort under rocprofv3"),
+    so the multi-worker legs would only repeat the single-worker ones: they are skipped."""
+    import whisper_trtllm_amd as w
+    return w.runtime.under_rocprof()
 
 
 def main():
@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--no-varlen", action="store_true", help="skip the variable-length (LibriSpeech-like) workload")
     ap.add_argument("--no-fp16-decoder", action="store_true", help="skip the fp16-engine (encoder + decoder) batch-16 measurement")
     ap.add_argument("--varlen-utterances", type=int, default=64, help="utterances per GPU in the variable-length workload")
+    ap.add_argument("--varlen-long", type=int, default=256, help="utterances per GPU of the LONGER variable-length run (continuous mode and "
+                    "length-sorted batches only): a 64-utterance workload is mostly ramp-down -- the last utterances decode beside empty slots")
     ap.add_argument("--no-two-workers", action="store_true", help="skip the two-workers-per-GPU figures (WhisperPipeline)")
     ap.add_argument("--workers", type=int, default=1, help="engine pairs per GPU for the TIMED steps (runtime.WhisperPipeline).  Default 1 = one batch in "
                     "flight per GPU, the configuration the metric is quoted on; N > 1 runs the K steps N at a time (N x batch utterances in flight) "
@@ -70,7 +72,18 @@ def main():
                     help="float16 = BASELINE config 4 (fp16 encoder + fp32 decoder); the headline metric is float32")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: map every rank onto the visible GPUs round-robin")
+    ap.add_argument("--all-legs", action="store_true", help="with --gpus N > 1: also run the secondary legs (default there: the timed headline leg only)")
     args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.all_legs:
+        # A multi-GPU run measures the scaling of the HEADLINE: the secondary legs (variable-length workload, batch 16, fp16 engines, up to
+        # 4 worker threads per rank, per-kernel rooflines, CPU baseline) only lengthen an 8-GPU lease for numbers that are read at N = 1.
+        args.no_varlen = args.no_batch16 = args.no_fp16_decoder = args.no_two_workers = args.no_roofline = args.no_cpu_baseline = True
+    if os.environ.get("WT_SAVE_MAPS"):   # tools/profile_round.sh: the module map of every profiled process, so that a crash trace is symbolisable
+        try:
+            import shutil
+            shutil.copyfile("/proc/self/maps", os.environ["WT_SAVE_MAPS"])
+        except OSError:
+            pass
     if under_rocprof():
         if args.workers > 1:
             raise SystemExit("bench.py --workers N > 1 cannot run under rocprofv3 (see under_rocprof)")
@@ -204,14 +217,56 @@ def main():
         by_length = w.sharding.length_sorted_batches(w.audio.valid_frames(vmel), B)
         row_steps = [s_ + 1 for s_ in eos_steps]
         el_order, el_sorted = time_groups(in_order), time_groups(by_length)
+        # ... and in ARRIVAL order through the continuous mode (wt_decoder_stream_*): B slots stay busy, every utterance stops at its own
+        # EOS and the kernel that sees it refills the slot from the waiting queue in the same step (runtime.transcribe_continuous)
+        cstats = {}
+        w.transcribe_continuous(enc, dec, vmel[:2 * B], slots=B, chunk=B, force_eos_steps=eos_steps[:2 * B])
+        barrier()
+        t = time.perf_counter()
+        cont_ids = w.transcribe_continuous(enc, dec, vmel, slots=B, chunk=B, force_eos_steps=eos_steps, stats=cstats)
+        torch.cuda.synchronize()
+        el_cont = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+        barrier()
+        assert [len(r) - 1 for r in cont_ids] == row_steps, "continuous mode: an utterance did not stop at its own EOS"
+        long_run = None
+        if args.varlen_long > n_utt:   # the same two plans over a workload long enough that the ramp-down is a small part of it
+            n_long = args.varlen_long
+            dur_l, eos_l = w.synthetic.librispeech_like_lengths(n_long, seed=1000 + rank, max_length=args.max_length)
+            lmel = torch.from_numpy(np.stack([w.synthetic.make_mel_padded(cfg, 7000 + rank * n_long + i, dur_l[i]) for i in range(n_long)])).cuda()
+            lstats = {}
+            barrier()
+            t = time.perf_counter()
+            ids_l = w.transcribe_continuous(enc, dec, lmel, slots=B, chunk=B, force_eos_steps=eos_l, stats=lstats)
+            torch.cuda.synchronize()
+            el_lc = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+            barrier()
+            assert [len(r) - 2 for r in ids_l] == eos_l
+            groups_l = w.sharding.length_sorted_batches(w.audio.valid_frames(lmel), B)
+            barrier()
+            t = time.perf_counter()
+            for g in groups_l:
+                dec.generate(enc(lmel[g]), force_eos_steps=[eos_l[i] for i in g])
+            torch.cuda.synchronize()
+            el_ls = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+            barrier()
+            long_run = {"utterances_per_gpu": n_long, "mean_decoder_steps": round(float(np.mean(eos_l)) + 1, 1),
+                        "dataset_order_continuous": {"value": round(30.0 * n_long * world / el_lc, 2), "slot_utilisation": round(lstats["slot_utilisation"], 4),
+                                                     "decoder_steps": lstats["steps"]},
+                        "length_sorted": {"value": round(30.0 * n_long * world / el_ls, 2),
+                                          "slot_utilisation": round(w.sharding.slot_utilisation([s_ + 1 for s_ in eos_l], groups_l), 4)}}
+            del lmel
         varlen = {"utterances_per_gpu": n_utt, "mean_duration_s": round(float(np.mean(dur)), 2), "mean_decoder_steps": round(float(np.mean(row_steps)), 1),
                   "max_decoder_steps": int(max(row_steps)),
                   "dataset_order": {"value": round(30.0 * n_utt * world / el_order, 2), "real_audio_s_per_s": round(float(np.sum(dur)) * world / el_order, 2),
                                     "slot_utilisation": round(w.sharding.slot_utilisation(row_steps, in_order), 4)},
                   "length_sorted": {"value": round(30.0 * n_utt * world / el_sorted, 2), "real_audio_s_per_s": round(float(np.sum(dur)) * world / el_sorted, 2),
                                     "slot_utilisation": round(w.sharding.slot_utilisation(row_steps, by_length), 4)},
+                  "dataset_order_continuous": {"value": round(30.0 * n_utt * world / el_cont, 2), "real_audio_s_per_s": round(float(np.sum(dur)) * world / el_cont, 2),
+                                               "slot_utilisation": round(cstats["slot_utilisation"], 4), "decoder_steps": cstats["steps"]},
+                  "long_run": long_run,
                   "note": "value = 30 s windows per second as in the headline; lengths modelled on LibriSpeech test-clean (no dataset on the box), "
-                          "EOS forced per row; rank r uses seed r"}
+                          "EOS forced per row; rank r uses seed r; dataset_order_continuous = arrival order through the continuous mode "
+                          "(slots refilled on the device the step an utterance stops)"}
         if not args.no_two_workers:
             # the same length-sorted batches handed to 2 and 4 WORKERS per GPU (runtime.WhisperPipeline: N engine pairs, N host threads,
             # N streams): one worker's MFMA-bound encoder and launch-latency-bound decode fill the gaps of the others' decodes.
@@ -281,6 +336,7 @@ def main():
                    "value_n32_decode_steps": round(value_n32, 2),
                    "value_batch16_per_gpu": round(value_b16, 2) if value_b16 else None,
                    "value_varlen": varlen["length_sorted"]["value"] if varlen else None,
+                   "value_varlen_continuous": varlen["dataset_order_continuous"]["value"] if varlen else None,
                    "value_varlen_4_workers": varlen["length_sorted_workers"]["4"] if varlen and "length_sorted_workers" in varlen else None,
                    "value_2_workers_per_gpu": varlen["headline_passes_workers"]["2"] if varlen and "headline_passes_workers" in varlen else None,
                    "value_4_workers_per_gpu": varlen["headline_passes_workers"]["4"] if varlen and "headline_passes_workers" in varlen else None,
@@ -311,16 +367,24 @@ def main():
         # dominant kernel by time: decoder cross-attention (streams the utterances' resident K/V once per step)
         bytes_cross = B * H * S * 64 * 4 * 2          # cross-KV bytes/step/utt / L, x B utterances per launch
         avg_cross = us_cross * 1e-6
-        traffic = None   # HBM bytes per launch from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
+        # HBM bytes per launch from the committed PMC passes (bench.py cannot run rocprofv3 on itself; tools/profile_round.sh pmc writes the
+        # file).  Reported only while the kernel source it was measured on is the one in the tree: a stale file yields traffic = null.
+        traffic, traffic_from = None, None
         try:
+            import hashlib
             t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_dominant_kernel.json")))
+            sha = hashlib.sha256(open(os.path.join(ROOT, "whisper-trtllm_amd", "csrc", "kernels_decoder.hip"), "rb").read()).hexdigest()[:16]
             if B == 8 and args.model == "whisper-medium.en":
-                traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                if t.get("kernels_decoder_sha16") == sha:
+                    traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                    traffic_from = f"profiles/pmc_traffic_dominant_kernel.json ({t.get('source', '')}; kernels_decoder.hip {sha})"
+                else:
+                    traffic_from = f"stale: profiles/pmc_traffic_dominant_kernel.json was measured on kernels_decoder.hip {t.get('kernels_decoder_sha16')}, the tree holds {sha}"
         except (OSError, KeyError, ValueError):
             pass
         ach = bytes_cross / avg_cross / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, S=1500)", "achieved": round(ach, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
                            "bytes_per_launch": bytes_cross, "avg_launch_us": round(avg_cross * 1e6, 2), "launches": 40 * L,
                            "timing": "hipGraph replay of the L per-layer launches over the resident caches, hipEvents on the launch stream"}
         F_, C = cfg["encoder_ffn_dim"], cfg["num_mel_bins"]

@@ -29,9 +29,11 @@ def parse_arguments():
     parser.add_argument("--engine_dir", type=str, default="whisper_outputs")
     parser.add_argument("--cache", type=str, default="librispeech.cache")
     parser.add_argument("--batch", type=int, default=8)
-    parser.add_argument("--batching", choices=["sorted", "dataset"], default="sorted",
-                        help="sorted (default): length-aware batches -- utterances ordered by the audio duration recovered from the "
-                             "log-mel's trailing padding, so a batch does not decode on behind one long row; dataset: contiguous order")
+    parser.add_argument("--batching", choices=["continuous", "sorted", "dataset"], default="continuous",
+                        help="continuous (default): dataset order through the continuous mode -- `--batch` decode slots stay busy, every "
+                             "utterance stops at its own EOS (as the reference's one-clip-at-a-time loop, cal_wer.py:249-287) and its slot is "
+                             "refilled on the device; sorted: length-aware batches (utterances ordered by the audio duration recovered from the "
+                             "log-mel's trailing padding); dataset: contiguous batches, each decoding to its longest row")
     parser.add_argument("--workers", type=int, default=2, help="engine pairs per GPU, each on its own stream and host thread (1 = one batch in "
                         "flight at a time; 2 fills the decode's launch-latency gaps with the other batch's work: ~1.4x)")
     parser.add_argument("--dist-backend", type=str, default=None, help="nccl (= RCCL) | gloo; default: nccl when every rank has its own GPU")
@@ -57,20 +59,32 @@ if __name__ == "__main__":
     pipe = tensorrt_llm.WhisperPipeline(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read(),
                                         open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config, workers=max(1, args.workers))
     tok = WhisperTokenDecoder.from_dir(args.whisper)
+    eos = config["eos_token_id"]
     with open(args.cache, "rb") as f:
         dataset = pickle.load(f)
-    if args.batching == "sorted":   # every rank gets the same mix of long and short batches (round-robin over the sorted batches)
+    indexed = []
+    if args.batching == "continuous":   # this rank's contiguous shard in arrival order; nothing to sort, no row waits for a neighbour
+        begin, end = tensorrt_llm.sharding.utterance_shard(len(dataset), world, rank)
+        for c0 in range(begin, end, 512):      # host -> device in chunks of 512 utterances (a log-mel is 0.96 MB)
+            idx = list(range(c0, min(c0 + 512, end)))
+            mels = torch.stack([torch.as_tensor(dataset[i][0], dtype=torch.float32) for i in idx]).cuda()
+            rows = pipe.transcribe_continuous(mels, slots=args.batch, chunk=args.batch)
+            indexed += list(zip(idx, tok.batch_decode([r.tolist() for r in rows], skip_special_tokens=True)))
+        groups = []
+    elif args.batching == "sorted":   # every rank gets the same mix of long and short batches (round-robin over the sorted batches)
         lengths = [tensorrt_llm.audio.valid_frames(torch.as_tensor(m, dtype=torch.float32))[0] for m, _ in dataset]
         groups = tensorrt_llm.sharding.length_sorted_batches(lengths, args.batch, world, rank)
     else:
         begin, end = tensorrt_llm.sharding.utterance_shard(len(dataset), world, rank)   # this rank's contiguous shard
         groups = [list(range(b0, b1)) for b0, b1 in tensorrt_llm.sharding.batches(begin, end, args.batch)]
-    indexed = []
     for c0 in range(0, len(groups), 64):      # host -> device in chunks of 64 batches (a log-mel is 0.96 MB), decoded `workers` at a time
         chunk = groups[c0:c0 + 64]
         mels = [torch.stack([torch.as_tensor(dataset[i][0], dtype=torch.float32) for i in g]).cuda() for g in chunk]
         for g, ids in zip(chunk, pipe.transcribe(mels)):
-            indexed += list(zip(g, tok.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)))
+            # a row of a batch pads on behind its own EOS until the longest row stops; the reference decodes one clip at a time and
+            # ends AT the EOS (run.py:219-226) -- cut there (only matters when pad_token_id is not a special token)
+            rows = [r[:r.index(eos, 1) + 1] if eos in r[1:] else r for r in ids.cpu().tolist()]
+            indexed += list(zip(g, tok.batch_decode(rows, skip_special_tokens=True)))
     indexed = sorted(tensorrt_llm.sharding.gather_objects(indexed, dist))            # back to dataset order on the host
     hypotheses = [h for _, h in indexed]
     references = [t for _, t in dataset]

@@ -42,8 +42,10 @@ def parse_arguments():
                         "front-end, i.e. what hf_processor does in the reference, run.py:267); with --whisper <checkpoint dir> the ids "
                         "are also decoded to text (vocab.json)")
     parser.add_argument("--max_length", type=int, default=None)
-    parser.add_argument("--batching", choices=["sorted", "dataset"], default="sorted",
-                        help="fast path: length-aware batches (by the audio duration recovered from the log-mel's trailing padding) or dataset order")
+    parser.add_argument("--batching", choices=["continuous", "sorted", "dataset"], default="sorted",
+                        help="fast path: continuous (arrival order, 8 decode slots refilled on the device the step an utterance stops -- every "
+                             "utterance ends at its own EOS like the reference's batch-1 loop, run.py:219-226), length-aware batches (by the audio "
+                             "duration recovered from the log-mel's trailing padding) or dataset-order batches")
     parser.add_argument("--workers", type=int, default=2, help="fast path: engine pairs per GPU, each on its own stream and host thread")
     parser.add_argument("--dist-backend", type=str, default=None, help="nccl (= RCCL) | gloo; default: nccl when every rank has its own GPU")
     parser.add_argument("--dump_ids", type=str, default=None, help="rank 0 writes the fast-path token ids as JSON (tests)")
@@ -155,7 +157,10 @@ if __name__ == "__main__":
     if not args.session:
         pipe = tensorrt_llm.WhisperPipeline(open(os.path.join(args.engine_dir, "WhisperEncoder.engine"), "rb").read(),
                                             open(os.path.join(args.engine_dir, "WhisperDecoder.engine"), "rb").read(), config, workers=max(1, args.workers))
-        if args.batching == "sorted":
+        begin, end = tensorrt_llm.sharding.utterance_shard(len(mels), world, rank)       # this rank's contiguous shard
+        if args.batching == "continuous":
+            groups = None
+        elif args.batching == "sorted":
             lengths = [tensorrt_llm.audio.valid_frames(m)[0] for m in mels]
             groups = tensorrt_llm.sharding.length_sorted_batches(lengths, 8, world, rank)
         else:
@@ -167,8 +172,12 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             t0 = time.time()
             indexed = []
-            for g, ids in zip(groups, pipe.transcribe([torch.cat([mels[i] for i in g]) for g in groups])):
-                indexed += list(zip(g, ids.cpu().tolist()))
+            if groups is None:
+                rows = pipe.transcribe_continuous(torch.cat(mels[begin:end]), slots=8, chunk=8) if end > begin else []
+                indexed = list(zip(range(begin, end), [r.tolist() for r in rows]))
+            else:
+                for g, ids in zip(groups, pipe.transcribe([torch.cat([mels[i] for i in g]) for g in groups])):
+                    indexed += list(zip(g, ids.cpu().tolist()))
             torch.cuda.synchronize()
             elapsed = tensorrt_llm.sharding.max_over_ranks(time.time() - t0, dist)
             ids = [row for _, row in sorted(tensorrt_llm.sharding.gather_objects(indexed, dist))]   # dataset order, on the host

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 2
+#define WT_ABI_VERSION 3
 
 /* error codes */
 #define WT_OK 0
@@ -157,6 +157,30 @@ int wt_decoder_read_ids(wt_engine* dec, int32_t* ids_out, int ld, void* stream);
  * max_length) to DEVICE memory and the final length to *out_len.  Synchronises the stream. */
 int wt_decoder_greedy(wt_engine* dec, const float* enc_hidden, int batch, const wt_greedy_params* p,
                       int32_t* ids_out, int* out_len, void* stream);
+
+/* ---- (10) continuous decoding: every utterance stops at its own EOS and its decode slot is refilled at once.
+ * The reference gets per-utterance stopping from transcribing one clip at a time (examples/whisper/run.py:219-226; dataset loop
+ * cal_wer.py:249-287); a batch started by wt_decoder_begin runs to its longest row.  Here `slots` rows (1..16) stay busy: utterances
+ * are submitted ahead of time (their cross K/V projected into a free row of a cache POOL of `pool_rows` rows, <= 256; 0 = 4 x slots),
+ * wait in a device-side queue, and the kernel that sees a row emit EOS (or reach max_length) puts the next waiting utterance into that
+ * slot within the same step.  Ids of every utterance equal those of the same utterance decoded alone.  Finished utterances are
+ * reported through pinned host memory: no device-to-host copy, no stream synchronisation.  logits_trace / force_eos_step(s) of `p`
+ * must be unset.  One stream per handle; wt_decoder_begin on the handle ends it. */
+int wt_decoder_stream_begin(wt_engine* dec, int slots, int pool_rows, const wt_greedy_params* p, void* stream);
+/* submit `n` (1..16) more utterances: enc_hidden f32 [n,S,d] on the device (consumed stream-ordered by this call's K/V projection).
+ * `force_eos_steps` (bench only, NULL = off): utterance i emits EOS at its own 0-based step force_eos_steps[i].  handles[i] receives
+ * the handle to collect utterance i with.  WT_E_STATE when fewer than n cache rows are free (collect finished utterances first).
+ * Utterances are admitted to slots in submission order.  Asynchronous. */
+int wt_decoder_stream_submit(wt_engine* dec, const float* enc_hidden, int n, const int32_t* force_eos_steps, int32_t* handles, void* stream);
+/* enqueue decoder steps (as wt_decoder_run: `lookahead` steps queued behind the running one, progress followed through the pinned
+ * mailbox) until every submitted utterance has finished -- or, with min_waiting > 0, until fewer than `min_waiting` submitted
+ * utterances are still waiting for a slot, so that the caller can submit more before a slot runs dry.  *n_finished = utterances
+ * finished since wt_decoder_stream_begin, *n_waiting = an upper bound of those still waiting, *n_steps = decoder steps enqueued since
+ * wt_decoder_stream_begin (each is `slots` row-steps: the denominator of the slot utilisation).  Any of the three may be NULL. */
+int wt_decoder_stream_run(wt_engine* dec, int min_waiting, int lookahead, int* n_finished, int* n_waiting, int* n_steps, void* stream);
+/* *len = length of utterance `handle` (start token and EOS included) once it has finished, 0 while it waits or decodes.  With ids_out
+ * != NULL (HOST memory, capacity `cap` >= *len int32) a finished utterance's ids are copied out and its cache row is released. */
+int wt_decoder_stream_collect(wt_engine* dec, int handle, int32_t* ids_out, int cap, int* len);
 
 /* per-phase device timers (hipEvents on the caller's stream) for bench.py's roofline block */
 typedef struct {

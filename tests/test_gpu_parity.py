@@ -422,3 +422,21 @@ def test_nan_in_one_utterance_keeps_every_id_in_range(wt, precision):
         want = cpu_ref.greedy_search(W, cfg, hidden.cpu(), fp16_engine=precision == "float16").numpy()
     np.testing.assert_array_equal(ids, want)
     assert (ids[1, 2:] == 0).all()
+
+
+def test_pipeline_runs_one_worker_under_the_profiler(wt, monkeypatch):
+    """a multi-worker pipeline under rocprofv3 aborted inside the runtime in round 3; the guard lives in WhisperPipeline itself
+    (runtime.under_rocprof), so run.py / cal_wer.py / tools/two_workers.py are covered: asked for 3 workers with the profiler's
+    environment present it builds ONE engine pair, and still returns every batch."""
+    cfg = wt.synthetic.get_config("toy-short")
+    weights = wt.synthetic.make_weights(cfg, 13)
+    eb, db = wt.convert.build_encoder_engine(cfg, weights), wt.convert.build_decoder_engine(cfg, weights)
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/none")
+    pipe = wt.WhisperPipeline(eb, db, cfg, workers=3)
+    assert len(pipe.engines) == 1 and len(pipe.streams) == 1
+    mels = [torch.from_numpy(wt.synthetic.make_mel(cfg, index=10 * i, batch=2)).cuda() for i in range(3)]
+    out = pipe.transcribe(mels)
+    monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
+    ref = wt.WhisperPipeline(eb, db, cfg, workers=2).transcribe(mels)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)

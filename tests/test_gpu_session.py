@@ -201,10 +201,13 @@ def _toy_vocabulary(cfg, ckpt):
     json.dump(vocab, open(ckpt / "vocab.json", "w", encoding="utf-8"), ensure_ascii=False)
 
 
-def test_cal_wer_script_end_to_end(wt, tmp_path):
+@pytest.mark.parametrize("batching", ["continuous", "sorted"])
+def test_cal_wer_script_end_to_end(wt, tmp_path, batching):
     """examples/whisper/cal_wer.py as a subprocess over artefacts this test writes itself: toy engines + config.pkl, a toy byte-level
     vocabulary, and a `librispeech.cache` of (log-mel, reference text) pairs — fast-path decode, token decode, English normaliser,
-    pooled WER.  The expected number is recomputed here from the same library calls."""
+    pooled WER.  The expected number is recomputed here from the same library calls.  Both plans -- continuous (the default: dataset
+    order, slots refilled on the device) and length-sorted batches -- must give the hypotheses of the reference's one-clip-at-a-time
+    loop: every row ends AT its EOS (this golden's pad token is an ordinary text token, so a row that padded on would show)."""
     import json
     import subprocess
     from whisper_trtllm_amd.english import EnglishTextNormalizer
@@ -221,13 +224,16 @@ def test_cal_wer_script_end_to_end(wt, tmp_path):
     enc = wt.WhisperEncoderEngine((eng / "WhisperEncoder.engine").read_bytes())
     dec = wt.WhisperDecoderEngine((eng / "WhisperDecoder.engine").read_bytes(), cfg)
     ids = dec.generate(enc(torch.from_numpy(mel).cuda())).cpu().tolist()
+    eos = cfg["eos_token_id"]
+    assert cfg["pad_token_id"] != eos and any(eos in r[1:-1] for r in ids)      # a row of this golden stops early and pads on in a batch
+    ids = [r[:r.index(eos, 1) + 1] if eos in r[1:] else r for r in ids]          # run.py:219-226: a clip decoded alone ends at its EOS
     hyp = WhisperTokenDecoder.from_dir(str(ckpt)).batch_decode(ids, skip_special_tokens=True)
     refs = [hyp[0], "twenty one colour " + hyp[1], "completely different words here"][:len(hyp)]
     pickle.dump([(mel[i], refs[i]) for i in range(len(refs))], open(tmp_path / "librispeech.cache", "wb"))
     norm = EnglishTextNormalizer({"colour": "color"})
     want = word_error_rate([norm(t) for t in refs], [norm(t) for t in hyp])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "whisper", "cal_wer.py"), "--whisper", str(ckpt), "--engine_dir", str(eng),
-                          "--cache", str(tmp_path / "librispeech.cache"), "--batch", "2"], capture_output=True, text=True, timeout=300)
+                          "--cache", str(tmp_path / "librispeech.cache"), "--batch", "2", "--batching", batching], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("WER:")][-1]
     assert abs(float(line.split()[1]) - want * 100) < 0.006, (line, want)

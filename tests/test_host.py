@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert names, header
         for n in sorted(names):
             assert hasattr(lib, n), f"{n} declared in {header} but not exported"
-    assert lib.wt_abi_version() == 2
+    assert lib.wt_abi_version() == 3
 
 
 def test_open_rejects_garbage_and_reports():
@@ -302,3 +302,17 @@ def test_pipeline_worker_dispatch_host_logic():
         return i
     with pytest.raises(KeyError):
         run_workers(50, 4, bad)
+
+
+def test_under_rocprof_detection(monkeypatch):
+    """runtime.under_rocprof(): the guard WhisperPipeline uses to clamp itself to one worker under rocprofv3."""
+    import whisper_trtllm_amd as w
+    for k in list(__import__("os").environ):
+        if k.startswith("ROCPROF_") or k in ("ROCP_TOOL_LIBRARIES", "LD_PRELOAD"):
+            monkeypatch.delenv(k, raising=False)
+    assert not w.runtime.under_rocprof()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert w.runtime.under_rocprof()
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert w.runtime.under_rocprof()

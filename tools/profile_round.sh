@@ -27,6 +27,7 @@ fi
 # ---- kernel traces (rocprofv3 --kernel-trace --stats), summaries by tools/prof_summary.py
 trace() {  # name, bench args...
     local name=$1; shift
+    export WT_SAVE_MAPS=$O/${TAG}_${name}_proc_maps.txt   # load addresses of every module of the profiled process: any crash trace of this run stays symbolisable
     step "kernel trace $name"
     rm -rf $O/${TAG}_trace_$name
     timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_$name -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-batch16 --no-varlen --no-fp16-decoder "$@" > $O/${TAG}_${name}_bench_under_rocprof.json 2> $O/${TAG}_trace_$name.err || return 1
@@ -57,6 +58,7 @@ if [ "$PHASE" = all ] || [ "$PHASE" = pmc ]; then
 pmc fetch FETCH_SIZE -- --max-length 12 || exit 1
 pmc write WRITE_SIZE -- --max-length 12 || exit 1
 python3 $R/tools/pmc_summary.py $(find $O/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc_write -name "*counter_collection.csv" | head -1) > $O/${TAG}_pmc_fetch_write_per_launch.txt
+python3 $R/tools/pmc_traffic_json.py $(find $O/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc_write -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_traffic_dominant_kernel.json "profiles/${TAG}_pmc_fetch_write_per_launch.txt" || exit 1
 pmc mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- --max-length 4 || exit 1
 python3 $R/tools/pmc_mfma.py $(find $O/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $(find $O/${TAG}_pmc_mfma -name "*kernel_trace.csv" | head -1) > $O/${TAG}_pmc_mfma_busy.txt
 pmc mfma16 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- --max-length 4 --encoder-precision float16 --batch 16 || exit 1

@@ -12,7 +12,7 @@ from .builder import Builder, BuilderConfig  # noqa: F401
 from .logger import logger  # noqa: F401
 from .models import WhisperDecoder, WhisperEncoder  # noqa: F401
 from .network import net_guard  # noqa: F401
-from .runtime import Session, TensorInfo, WhisperDecoderEngine, WhisperEncoderEngine, WhisperPipeline  # noqa: F401
+from .runtime import DecodeStream, Session, TensorInfo, WhisperDecoderEngine, WhisperEncoderEngine, WhisperPipeline, transcribe_continuous  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -12,12 +12,13 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_float, c_int, c_int32
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libwhisper_trtllm_amd.so")
 WT_NAME_LEN, WT_MAX_DIMS = 48, 6
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = [
     "wt_engine_open", "wt_engine_clone", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
     "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_run", "wt_decoder_read_ids",
-    "wt_decoder_greedy", "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
+    "wt_decoder_greedy", "wt_decoder_stream_begin", "wt_decoder_stream_submit", "wt_decoder_stream_run", "wt_decoder_stream_collect",
+    "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
 DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_decode_attention",
@@ -91,6 +92,10 @@ def load():
     lib.wt_decoder_run.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_void_p]
     lib.wt_decoder_read_ids.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
     lib.wt_decoder_greedy.argtypes = [c_void_p, c_void_p, c_int, POINTER(GreedyParams), c_void_p, POINTER(c_int), c_void_p]
+    lib.wt_decoder_stream_begin.argtypes = [c_void_p, c_int, c_int, POINTER(GreedyParams), c_void_p]
+    lib.wt_decoder_stream_submit.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int32), POINTER(c_int32), c_void_p]
+    lib.wt_decoder_stream_run.argtypes = [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p]
+    lib.wt_decoder_stream_collect.argtypes = [c_void_p, c_int, POINTER(c_int32), c_int, POINTER(c_int)]
     lib.wt_engine_set_profiling.argtypes = [c_void_p, c_int]
     lib.wt_engine_get_timer.argtypes = [c_void_p, c_char_p, POINTER(KernelTimer)]
     lib.wt_logmel_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p)]

@@ -114,18 +114,30 @@ struct wt_engine {
     unsigned long long* mailbox_dev = nullptr;  // its device address
     int epoch = 0;                // wt_decoder_begin count (tags the mailbox word: late no-op steps of the previous decode are ignored)
     int issued = 0;               // decoder steps enqueued since wt_decoder_begin
+    // continuous mode (wt_decoder_stream_*): the cross caches are a POOL of rows, `B` decode slots take utterances from a device queue
+    int cross_rows = 0;           // rows per layer of the resident cross caches (>= dec_cap; the pool of the continuous mode)
+    bool stream_mode = false;
+    int pool_rows = 0;            // pool rows the current stream may use (<= cross_rows)
+    int* h_ids = nullptr;         // pinned, coherent [h_pool_cap][h_ml_cap]: ids of the utterance in pool row r (written by stream_finish_kernel)
+    int* h_len = nullptr;         // pinned, coherent [h_pool_cap]: its final length, 0 = still waiting / decoding
+    int *h_ids_dev = nullptr, *h_len_dev = nullptr;
+    int h_pool_cap = 0, h_ml_cap = 0;
+    std::vector<char> pool_state; // host allocator of pool rows: 0 free, 1 submitted (waiting or decoding), 2 finished but not collected
+    int submitted = 0, finished_seen = 0, admitted_seen = 0;
     int* force_rows = nullptr;    // device [16]: per-row forced-EOS steps (bench-only variable-length workload)
     std::vector<int> h_force_rows;
     bool force_rows_on = false;
     // greedy session
     bool begun = false;
-    int B = 0, max_length = 0, begin_index = 0, eos = 0, pad = 0, force_eos_step = -1, nsplit_self = 1, nsplit_cross = 4;
+    int B = 0, max_length = 0, begin_index = 0, eos = 0, pad = 0, force_eos_step = -1, nsplit_self = 1, nsplit_cross = 4, start_token = 0;
     float* trace = nullptr;
     hipStream_t own_stream = nullptr;
-    // step graphs: [0] every row attends (the only one a decode without early finishers ever replays), [1] finished rows stream no K/V
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-    bool graph_ok[2] = {false, false};
+    // step graphs: [0] every row attends (the only one a decode without early finishers ever replays), [1] finished rows stream no K/V,
+    // [2] / [3] the same two for the continuous mode (per-slot cross-cache rows, stream_finish_kernel)
+    static constexpr int N_GRAPHS = 4;
+    hipGraph_t graph[N_GRAPHS] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t graph_exec[N_GRAPHS] = {nullptr, nullptr, nullptr, nullptr};
+    bool graph_ok[N_GRAPHS] = {false, false, false, false};
     bool graph_valid = false, use_graph = true;
     int nt_loads = 1;  // stream weights and K/V with non-temporal loads (set per decode in wt_decoder_begin)
     // Session-compat shapes (set by infer_shapes)
@@ -178,7 +190,7 @@ extern "C" const char* wt_last_error(void) { return g_err; }
 extern "C" void wt_engine_close(wt_engine* e) {
     if (!e) return;
     DeviceGuard guard(e->device);
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < wt_engine::N_GRAPHS; ++v) {
         if (e->graph_exec[v]) hipGraphExecDestroy(e->graph_exec[v]);
         if (e->graph[v]) hipGraphDestroy(e->graph[v]);
     }
@@ -192,6 +204,8 @@ extern "C" void wt_engine_close(wt_engine* e) {
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     if (e->h_state) hipHostFree(e->h_state);
     if (e->mailbox) hipHostFree((void*)e->mailbox);
+    if (e->h_ids) hipHostFree(e->h_ids);
+    if (e->h_len) hipHostFree(e->h_len);
     if (e->enc_ws) hipFree(e->enc_ws);
     if (e->dec_ws) hipFree(e->dec_ws);
     e->weights.reset();   // the last handle sharing the payload frees it
@@ -502,17 +516,21 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
 }
 
 // ------------------------------------------------------------------------------------------------- decoder
-static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s) {
-    if (B <= e->dec_cap && max_length <= e->dec_maxlen_cap) return WT_OK;
-    if (e->dec_ws) { hipFree(e->dec_ws); e->dec_ws = nullptr; e->dec_cap = 0; }
+static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s, int pool_rows = 0) {
+    if (B <= e->dec_cap && max_length <= e->dec_maxlen_cap && pool_rows <= e->cross_rows) return WT_OK;
+    if (B < e->dec_cap) B = e->dec_cap;                      // never shrink: a later, smaller call keeps what an earlier one needed
+    if (max_length < e->dec_maxlen_cap) max_length = e->dec_maxlen_cap;
+    if (pool_rows < e->cross_rows) pool_rows = e->cross_rows;
+    if (e->dec_ws) { hipFree(e->dec_ws); e->dec_ws = nullptr; e->dec_cap = 0; e->cross_rows = 0; }
     e->graph_valid = false;
     e->tables_valid = false;
     const int cap_len = max_length > e->T ? max_length : e->T;
-    const size_t d = e->d, kv_self = (size_t)e->L * B * e->H * e->T * HEAD_DIM, kv_cross = (size_t)e->L * B * e->H * e->S * HEAD_DIM;
+    const int cross_rows = pool_rows > B ? pool_rows : B, enc_rows = B > MAX_ROWS ? B : MAX_ROWS;
+    const size_t d = e->d, kv_self = (size_t)e->L * B * e->H * e->T * HEAD_DIM, kv_cross = (size_t)e->L * cross_rows * e->H * e->S * HEAD_DIM;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_sk = take(kv_self * e->kv_esz), o_sv = take(kv_self * e->kv_esz), o_ck = take(kv_cross * e->kv_esz), o_cv = take(kv_cross * e->kv_esz);
-    const size_t o_ench = take(e->w_half ? (size_t)B * e->S * d * 2 : 0);
+    const size_t o_ench = take(e->w_half ? (size_t)enc_rows * e->S * d * 2 : 0);
     const size_t o_h = take((size_t)B * d * 4), o_h2 = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
     const size_t o_cnt = take((size_t)B * e->H * 4);
     const size_t o_selv = take((size_t)B * SEL_PARTS_CAP * 4), o_seli = take((size_t)B * SEL_PARTS_CAP * 4);
@@ -540,6 +558,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s) {
     }
     HIPCHK(hipStreamSynchronize(s));   // as in enc_reserve: the ticket clear above is ordered before any later call on any stream
     e->dec_cap = B;
+    e->cross_rows = cross_rows;
     e->dec_maxlen_cap = cap_len;
     return WT_OK;
 }
@@ -559,7 +578,9 @@ static int pick_splits(int B, int H, int len) {
 struct StepIO {
     const int* ids; int ids_ld;            // token fed to row b = ids[b*ids_ld + st->cur_len-1]
     float *self_k, *self_v; int self_cap;  // layer stride = B*H*self_cap*64 elements
-    float *cross_k, *cross_v;              // layer stride = B*H*S*64 elements
+    float *cross_k, *cross_v;              // layer stride = cross_rows*H*S*64 elements
+    int cross_rows;                        // cache rows per layer (the engine's resident pool; 1 on the Session path)
+    const int* slot_row;                   // continuous mode: slot b attends over cache row slot_row[b] (DecAttnParams.slot_row)
     int kv_esz;                            // bytes per cache element: 4 (fp32; always on the Session path), 2 (resident caches of an fp16 engine)
     float* logits;                         // [B][V]
     int B, nsplit_self, nsplit_cross;
@@ -578,7 +599,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     static const bool defer = tuning_env("WT_NO_DEFER_MERGE") == nullptr;  // A/B switch
     const int d = e->d, B = io.B, H = e->H;
     const DecLayerW& l = e->dec_layers[i];
-    const size_t self_layer = (size_t)i * B * H * io.self_cap * HEAD_DIM * io.kv_esz, cross_layer = (size_t)i * B * H * e->S * HEAD_DIM * io.kv_esz;
+    const size_t self_layer = (size_t)i * B * H * io.self_cap * HEAD_DIM * io.kv_esz, cross_layer = (size_t)i * io.cross_rows * H * e->S * HEAD_DIM * io.kv_esz;
     float* sk = (float*)((char*)io.self_k + self_layer);
     float* sv = (float*)((char*)io.self_v + self_layer);
     const float* ck = (const float*)((const char*)io.cross_k + cross_layer);
@@ -619,7 +640,7 @@ static int enqueue_layer_part(wt_engine* e, const StepIO& io, int i, float* h, f
     case LP_CROSS_ATTN: {  // cross attention over the encoder memory: K/V already resident
         a.q = e->dq; a.kcache = ck; a.vcache = cv; a.part = e->part; a.cnt = e->att_cnt; a.out = e->datt; a.st = e->st; a.B = B; a.H = H; a.s_cap = e->S;
         a.n_split = io.nsplit_cross; a.fixed_len = e->S; a.nt = e->nt_loads; a.ln_h = h1; a.ln_r = l.fold_r; a.ln_t = l.fold_t; a.kv_half = kvh;
-        a.alive = io.alive;
+        a.alive = io.alive; a.slot_row = io.slot_row;
         a.defer_merge = defer && io.nsplit_cross == 2;  // the out-projection below merges the two split partials while staging them
                                                         // (more splits, i.e. batch < 8: the attention kernel merges its own, by ticket)
         hipEvent_t ta, tb;
@@ -687,14 +708,18 @@ static int enqueue_step(wt_engine* e, const StepIO& io, hipStream_t s) {
 }
 
 static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int rows, int seq_off, float* ck, float* cv, int kv_esz,
-                            hipStream_t s) {
+                            hipStream_t s, int layer_rows = 0, int row0 = 0) {
     // K/V projection of encoder rows [0, rows) of every utterance into cache rows [seq_off, seq_off+rows).  fp16 engines: the encoder
     // memory is rounded to fp16 once (the MFMA's A operand), the product accumulates in fp32 and lands in the caches as `kv_esz` says.
+    // The caches hold `layer_rows` utterance rows per layer (default B); the B utterances land in rows [row0, row0 + B).
     const int d = e->d;
+    if (layer_rows <= 0) layer_rows = B;
+    if (row0 < 0 || row0 + B > layer_rows) return fail(WT_E_INVALID, "cross_kv_project: rows [%d, %d) outside a cache of %d rows per layer", row0, row0 + B, layer_rows);
+    const size_t row_bytes = (size_t)e->H * e->S * HEAD_DIM * kv_esz;
     if (e->w_half) LAUNCH(launch_cast_h(enc_hidden, e->enc_h, (size_t)B * e->S * d, s));
     for (int i = 0; i < e->L; ++i) {
         const DecLayerW& l = e->dec_layers[i];
-        const size_t layer = (size_t)i * B * e->H * e->S * HEAD_DIM * kv_esz;
+        const size_t layer = ((size_t)i * layer_rows + row0) * row_bytes;
         GemmParams g;
         memset(&g, 0, sizeof g);
         g.A = e->w_half ? (const float*)e->enc_h : enc_hidden; g.lda = d; g.a_rows_per_batch = rows; g.a_batch_stride = (long long)e->S * d;
@@ -714,18 +739,15 @@ static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int ro
     return WT_OK;
 }
 
-extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, const wt_greedy_params* p, void* stream) {
-    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_begin: not a decoder engine");
-    if (!enc_hidden || !p || B < 1) return fail(WT_E_INVALID, "wt_decoder_begin: bad arguments");
-    if (B > 16) return fail(WT_E_UNSUPPORTED, "wt_decoder_begin: batch %d > 16 per call; shard the batch", B);
+// Everything wt_decoder_begin and wt_decoder_stream_begin share: argument checks, workspace, token-rule tables, cache policy and key
+// splits of the step graph.  `B` = rows of the batch / decode slots of the stream; `pool_rows` = cross-cache rows (0: B).
+static int decode_setup(wt_engine* e, int B, const wt_greedy_params* p, int pool_rows, bool stream_mode, hipStream_t s, const char* who) {
+    if (B > MAX_ROWS) return fail(WT_E_UNSUPPORTED, "%s: batch %d > %d per call; shard the batch", who, B, MAX_ROWS);
     if (p->max_length < 2 || p->max_length > e->T) return fail(WT_E_INVALID, "max_length %d outside [2, max_target_positions=%d]", p->max_length, e->T);
     auto tok_ok = [&](int t) { return t >= 0 && t < e->V; };
     if (!tok_ok(p->decoder_start_token_id) || !tok_ok(p->eos_token_id) || !tok_ok(p->pad_token_id))
         return fail(WT_E_INVALID, "start/eos/pad token id outside the vocabulary");
-    DeviceGuard guard(e->device);
-    HIPCHK(guard.err);
-    hipStream_t s = (hipStream_t)stream;
-    int rc = dec_reserve(e, B, p->max_length, s);
+    int rc = dec_reserve(e, B, p->max_length, s, pool_rows);
     if (rc) return rc;
     // token rules -> device tables (SuppressTokens / SuppressTokensAtBegin / ForceTokens).  The host images live in the engine:
     // when the rules are the ones of the previous decode (the usual case: one rule set per checkpoint) nothing is uploaded and
@@ -756,7 +778,7 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     }
     {   // bench-only per-row transcript lengths: uploaded (with one synchronisation) only when they change
         std::vector<int> rows;
-        if (p->force_eos_steps) rows.assign(p->force_eos_steps, p->force_eos_steps + B);
+        if (p->force_eos_steps && !stream_mode) rows.assign(p->force_eos_steps, p->force_eos_steps + B);
         const bool on = !rows.empty();
         if (on && rows != e->h_force_rows) {
             e->h_force_rows.swap(rows);
@@ -768,10 +790,10 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     }
     const bool same = e->begun && e->B == B && e->max_length == p->max_length && e->trace == p->logits_trace &&
                       e->begin_index == p->begin_index && e->eos == p->eos_token_id && e->pad == p->pad_token_id &&
-                      e->force_eos_step == p->force_eos_step;
+                      e->force_eos_step == p->force_eos_step && e->start_token == p->decoder_start_token_id;
     if (!same) e->graph_valid = false;
     e->B = B; e->max_length = p->max_length; e->begin_index = p->begin_index; e->eos = p->eos_token_id;
-    e->pad = p->pad_token_id; e->force_eos_step = p->force_eos_step; e->trace = p->logits_trace;
+    e->pad = p->pad_token_id; e->force_eos_step = p->force_eos_step; e->trace = p->logits_trace; e->start_token = p->decoder_start_token_id;
     // measured (tools/microbench.py, medium.en B=8): self attention is fastest unsplit at every length <= 448;
     // cross attention (1500 keys) with ~one block per CU
     {   // Everything a step touches is read exactly once per step: stream it non-temporally -- unless one whole step (weights + this
@@ -797,23 +819,27 @@ extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, co
     e->nsplit_cross = tuning_env("WT_NSPLIT_CROSS") ? atoi(tuning_env("WT_NSPLIT_CROSS")) : pick_splits(B, e->H, e->S);
     e->epoch = e->epoch % 0xffff + 1;   // 1..65535: never the value of a freshly zeroed mailbox
     e->issued = 0;
+    e->stream_mode = stream_mode;
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_begin(wt_engine* e, const float* enc_hidden, int B, const wt_greedy_params* p, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_begin: not a decoder engine");
+    if (!enc_hidden || !p || B < 1) return fail(WT_E_INVALID, "wt_decoder_begin: bad arguments");
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = decode_setup(e, B, p, 0, false, s, "wt_decoder_begin");
+    if (rc) return rc;
     LAUNCH(launch_dec_init(e->st, e->ids, e->unfinished, B, p->max_length, p->decoder_start_token_id, e->epoch, s));
     LAUNCH(launch_dec_embed(e->ids, p->max_length, e->tok_emb, e->pos_emb, e->dh, B, e->d, e->st, s, e->w_half));  // input of step 0
-    rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, e->kv_esz, s);
+    rc = cross_kv_project(e, enc_hidden, B, e->S, 0, e->cross_k, e->cross_v, e->kv_esz, s, e->cross_rows, 0);
     if (rc) return rc;
     e->begun = true;
     return WT_OK;
 }
 
-static int enqueue_fast_step(wt_engine* e, hipStream_t s, int variant = 0) {
-    StepIO io;
-    io.alive = variant == 1 ? e->unfinished : nullptr;
-    io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
-    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
-    io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
-    io.embed = false;  // dh already holds this step's input: written by wt_decoder_begin (step 0) or by the previous greedy_finish
-    static const bool fuse = tuning_env("WT_NO_FUSED_ARGMAX") == nullptr;  // A/B switch: logits to HBM + greedy_select_kernel
-    SelectParams sp;
+static void fill_select_params(wt_engine* e, SelectParams& sp) {
     memset(&sp, 0, sizeof sp);
     sp.logits = e->logits; sp.mask = e->mask; sp.forced = e->forced; sp.ids = e->ids; sp.unfinished = e->unfinished;
     sp.st = e->st; sp.trace = e->trace; sp.B = e->B; sp.V = e->V; sp.max_length = e->max_length;
@@ -821,6 +847,24 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s, int variant = 0) {
     sp.part_val = e->sel_val; sp.part_idx = e->sel_idx; sp.tok_emb = e->tok_emb; sp.pos_emb = e->pos_emb; sp.next_x = e->dh;
     sp.d_model = e->d; sp.n_parts = 8; sp.fused = 0; sp.emb_half = e->w_half;
     sp.force_eos_rows = e->force_rows_on ? e->force_rows : nullptr; sp.mailbox = e->mailbox_dev;
+    sp.start_token = e->start_token;
+    if (e->stream_mode) {
+        sp.stream = 1; sp.host_ids = e->h_ids_dev; sp.host_len = e->h_len_dev; sp.force_eos_step = -1; sp.force_eos_rows = nullptr; sp.trace = nullptr;
+    }
+}
+
+// variant bit 0: finished / idle rows stream no K/V (`alive`); bit 1: the continuous mode's graph (per-slot cross-cache rows and state)
+static int enqueue_fast_step(wt_engine* e, hipStream_t s, int variant = 0) {
+    StepIO io;
+    io.alive = (variant & 1) ? e->unfinished : nullptr;
+    io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
+    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.cross_rows = e->cross_rows; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
+    io.slot_row = (variant & 2) ? e->st->slot_row : nullptr;   // (address arithmetic on a device pointer: nothing is dereferenced here)
+    io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross;
+    io.embed = false;  // dh already holds this step's input: written by wt_decoder_begin (step 0) or by the previous greedy_finish
+    static const bool fuse = tuning_env("WT_NO_FUSED_ARGMAX") == nullptr;  // A/B switch: logits to HBM + greedy_select_kernel
+    SelectParams sp;
+    fill_select_params(e, sp);
     int parts = 0;
     io.argmax = fuse ? &sp : nullptr;
     io.argmax_parts = &parts;
@@ -831,11 +875,18 @@ static int enqueue_fast_step(wt_engine* e, hipStream_t s, int variant = 0) {
     return WT_OK;
 }
 
+// Captures and instantiations are rare (once per engine and decode configuration) and serialised process-wide: several host threads
+// drive their own handles concurrently (runtime.WhisperPipeline), and a multi-worker run under rocprofv3 aborted inside the runtime
+// while captures overlapped.  Replays (hipGraphLaunch) stay concurrent.  (What that does and does not explain of the round-3 abort:
+// DESIGN.md "The four-worker abort under rocprofv3".)
+static std::mutex g_capture_mutex;
+
 // enqueue n_steps decoder steps on `s` (the caller holds the device guard).  variant 1: the step graph in which finished rows stream
 // no K/V (wt_decoder_run switches to it once the mailbox reports a finished row; never with a logits trace, which records every
-// row's logits at every step as the reference computes them).
+// row's logits at every step as the reference computes them).  The continuous mode replays variants 2 / 3.
 static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant = 0) {
     if (e->trace) variant = 0;
+    if (e->stream_mode) variant |= 2;
     if (e->profiling || !e->use_graph) {  // eager: per-kernel event timers need real launches
         for (int i = 0; i < n_steps; ++i) {
             int rc = enqueue_fast_step(e, s, variant);
@@ -848,7 +899,7 @@ static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant =
     // capturing executes nothing) and REPLAYED on the caller's stream: a replay on a second stream measured 5 % slower
     // per step (1.69 vs 1.60 ms, medium.en B=8) than on the stream the rest of the pass already runs on.
     if (!e->graph_valid) {
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < wt_engine::N_GRAPHS; ++v) {
             if (e->graph_exec[v]) { hipGraphExecDestroy(e->graph_exec[v]); e->graph_exec[v] = nullptr; }
             if (e->graph[v]) { hipGraphDestroy(e->graph[v]); e->graph[v] = nullptr; }
             e->graph_ok[v] = false;
@@ -856,23 +907,197 @@ static int enqueue_steps(wt_engine* e, int n_steps, hipStream_t s, int variant =
         e->graph_valid = true;
     }
     if (!e->graph_ok[variant]) {
-        // Captures and instantiations are rare (once per engine and decode configuration) and serialised process-wide: several host
-        // threads drive their own handles concurrently (runtime.WhisperPipeline), and a multi-worker run under rocprofv3 crashed
-        // inside the runtime with two captures in flight at once.  Replays (hipGraphLaunch) stay concurrent.
-        static std::mutex capture_mutex;
-        std::lock_guard<std::mutex> lock(capture_mutex);
+        std::lock_guard<std::mutex> lock(g_capture_mutex);
+        if (e->graph[variant]) { hipGraphDestroy(e->graph[variant]); e->graph[variant] = nullptr; }   // left by a failed attempt
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_fast_step(e, e->own_stream, variant);
         hipError_t ce = hipStreamEndCapture(e->own_stream, &e->graph[variant]);
-        if (rc) return rc;
-        if (ce != hipSuccess) return fail(WT_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-        HIPCHK(hipGraphInstantiate(&e->graph_exec[variant], e->graph[variant], nullptr, nullptr, 0));
+        if (rc != WT_OK || ce != hipSuccess) {
+            if (e->graph[variant]) { hipGraphDestroy(e->graph[variant]); e->graph[variant] = nullptr; }
+            return rc != WT_OK ? rc : fail(WT_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        }
+        const hipError_t ie = hipGraphInstantiate(&e->graph_exec[variant], e->graph[variant], nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            hipGraphDestroy(e->graph[variant]);
+            e->graph[variant] = nullptr;
+            e->graph_exec[variant] = nullptr;
+            return fail(WT_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+        }
         e->graph_ok[variant] = true;
     }
     for (int i = 0; i < n_steps; ++i) {
         HIPCHK(hipGraphLaunch(e->graph_exec[variant], s));
         e->issued += 1;   // counted only once it is really in the queue: wt_decoder_run compares it with the steps the mailbox reports
     }
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- continuous decoding
+// The reference transcribes one clip at a time, so every utterance stops at its own EOS (run.py:219-226; dataset loop cal_wer.py:249-287).
+// A batch started by wt_decoder_begin runs to its LONGEST row.  The continuous mode keeps `slots` rows busy instead: utterances are
+// SUBMITTED (their cross K/V projected into a free row of a cache pool, any number ahead of time), wait in a device queue, and the
+// kernel that sees a row stop puts the next waiting utterance into that slot in the same step -- no finished row is ever stepped, no
+// host round trip sits between an EOS and the next utterance's first token.  Finished utterances report through pinned host memory.
+extern "C" int wt_decoder_stream_begin(wt_engine* e, int slots, int pool_rows, const wt_greedy_params* p, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_stream_begin: not a decoder engine");
+    if (!p || slots < 1) return fail(WT_E_INVALID, "wt_decoder_stream_begin: bad arguments");
+    if (pool_rows <= 0) pool_rows = 4 * slots;     // slots decoding + 3 x slots prepared ahead
+    if (pool_rows < slots + 1 || pool_rows > STREAM_QCAP) return fail(WT_E_INVALID, "wt_decoder_stream_begin: pool of %d rows outside [slots + 1, %d]", pool_rows, STREAM_QCAP);
+    if (p->logits_trace || p->force_eos_step >= 0 || p->force_eos_steps)
+        return fail(WT_E_UNSUPPORTED, "wt_decoder_stream_begin: logits_trace / force_eos_step(s) belong to wt_decoder_begin (per-utterance lengths: wt_decoder_stream_submit)");
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = decode_setup(e, slots, p, pool_rows, true, s, "wt_decoder_stream_begin");
+    if (rc) return rc;
+    if (pool_rows > e->h_pool_cap || e->dec_maxlen_cap > e->h_ml_cap) {   // pinned report area: ids and final lengths per pool row
+        HIPCHK(hipStreamSynchronize(s));   // no step of an earlier stream may still write the old area
+        const int rows = pool_rows > e->h_pool_cap ? pool_rows : e->h_pool_cap;
+        if (e->h_ids) { hipHostFree(e->h_ids); e->h_ids = nullptr; }
+        if (e->h_len) { hipHostFree(e->h_len); e->h_len = nullptr; }
+        e->h_pool_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&e->h_ids, (size_t)rows * e->dec_maxlen_cap * 4, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostMalloc((void**)&e->h_len, (size_t)rows * 4, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_ids_dev, e->h_ids, 0));
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_len_dev, e->h_len, 0));
+        e->h_pool_cap = rows;
+        e->h_ml_cap = e->dec_maxlen_cap;
+        e->graph_valid = false;   // the step graph carries these addresses
+    }
+    e->pool_rows = pool_rows;
+    e->pool_state.assign(pool_rows, 0);
+    e->submitted = e->finished_seen = e->admitted_seen = 0;
+    for (int r = 0; r < pool_rows; ++r) __atomic_store_n(e->h_len + r, 0, __ATOMIC_RELAXED);
+    LAUNCH(launch_stream_init(e->st, e->unfinished, slots, e->epoch, s));
+    e->begun = true;
+    return WT_OK;
+}
+
+extern "C" int wt_decoder_stream_submit(wt_engine* e, const float* enc_hidden, int n, const int32_t* force_eos_steps, int32_t* handles,
+                                        void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER || !e->begun || !e->stream_mode) return fail(WT_E_STATE, "wt_decoder_stream_submit: no stream open (wt_decoder_stream_begin)");
+    if (!enc_hidden || !handles || n < 1 || n > MAX_ROWS) return fail(WT_E_INVALID, "wt_decoder_stream_submit: 1 .. %d utterances per call", MAX_ROWS);
+    if (e->submitted - e->admitted_seen + n > STREAM_QCAP) return fail(WT_E_STATE, "wt_decoder_stream_submit: waiting queue full");
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    hipStream_t s = (hipStream_t)stream;
+    // pool rows for the n utterances: as few contiguous runs as the free list allows (one batched K/V projection per run and layer)
+    std::vector<int> rows;
+    for (int r = 0; r < e->pool_rows && (int)rows.size() < n; ++r)
+        if (e->pool_state[r] == 0) rows.push_back(r);
+    if ((int)rows.size() < n) return fail(WT_E_STATE, "wt_decoder_stream_submit: %d free cache rows for %d utterances (collect finished ones first)", (int)rows.size(), n);
+    StreamPublish pub;
+    memset(&pub, 0, sizeof pub);
+    pub.n = n;
+    for (int i = 0; i < n; ++i) {
+        pub.rows[i] = rows[i];
+        pub.force[i] = force_eos_steps ? force_eos_steps[i] : -1;
+        handles[i] = rows[i];
+    }
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        while (j < n && rows[j] == rows[j - 1] + 1) ++j;
+        const int rc = cross_kv_project(e, enc_hidden + (size_t)i * e->S * e->d, j - i, e->S, 0, e->cross_k, e->cross_v, e->kv_esz, s, e->cross_rows, rows[i]);
+        if (rc) return rc;
+        i = j;
+    }
+    for (int i = 0; i < n; ++i) {
+        __atomic_store_n(e->h_len + rows[i], 0, __ATOMIC_RELAXED);   // (the row is free: no kernel writes it before the publish below)
+        e->pool_state[rows[i]] = 1;
+    }
+    SelectParams sp;
+    fill_select_params(e, sp);
+    LAUNCH(launch_stream_publish(sp, pub, s));
+    e->submitted += n;
+    return WT_OK;
+}
+
+// newly finished utterances (their pinned length word has become non-zero): state 1 -> 2
+static int stream_scan_finished(wt_engine* e) {
+    int n = 0;
+    for (int r = 0; r < e->pool_rows; ++r)
+        if (e->pool_state[r] == 1 && __atomic_load_n(e->h_len + r, __ATOMIC_ACQUIRE) != 0) {
+            e->pool_state[r] = 2;
+            ++n;
+        }
+    e->finished_seen += n;
+    return n;
+}
+
+// Steps until (a) every submitted utterance has finished, or (b) fewer than `min_waiting` submitted utterances are still waiting for a
+// slot (min_waiting > 0: the caller has more to submit and wants the queue topped up).  Follows the mailbox like wt_decoder_run.
+extern "C" int wt_decoder_stream_run(wt_engine* e, int min_waiting, int lookahead, int* n_finished, int* n_waiting, int* n_steps, void* stream) {
+    if (!e || e->kind != WT_KIND_DECODER || !e->begun || !e->stream_mode) return fail(WT_E_STATE, "wt_decoder_stream_run: no stream open (wt_decoder_stream_begin)");
+    DeviceGuard guard(e->device);
+    HIPCHK(guard.err);
+    hipStream_t s = (hipStream_t)stream;
+    if (lookahead <= 0) lookahead = e->nt_loads ? 1 : 3;
+    if (lookahead > 64) lookahead = 64;
+    int spins = 0, slices = 0;
+    unsigned long long last = ~0ull;
+    for (;;) {
+        const unsigned long long mb = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
+        const bool mine = (int)(mb >> 48) == e->epoch;
+        const int retired = mine ? e->issued - (int)((unsigned)(e->issued - (int)((mb >> 32) & 0xffff)) & 0xffffu) : 0;
+        if (mine) {   // admitted utterances: the word carries the low 15 bits of the device's count
+            const int adm = (int)((mb >> 16) & 0x7fff);
+            e->admitted_seen += (int)((unsigned)(adm - e->admitted_seen) & 0x7fffu);
+            if (e->admitted_seen > e->submitted) e->admitted_seen = e->submitted;
+        }
+        if (mb != last) {
+            last = mb;
+            stream_scan_finished(e);
+        }
+        const int waiting_ub = e->submitted - e->admitted_seen;   // upper bound: admissions by the publish kernel show up with the next step's word
+        if (e->finished_seen >= e->submitted) break;
+        if (min_waiting > 0 && waiting_ub < min_waiting) break;
+        if (e->issued - retired <= lookahead) {
+            // idle slots with nothing waiting (the tail of the workload): the graph whose attention skips them
+            const unsigned full = (1u << e->B) - 1u;
+            const int variant = (mine && retired > 0 && ((unsigned)mb & 0xffffu) != full && waiting_ub == 0) ? 1 : 0;
+            const int rc = enqueue_steps(e, 1, s, variant);
+            if (rc) return rc;
+            spins = slices = 0;
+            continue;
+        }
+        if (spins < 2000) {
+            ++spins;
+            __builtin_ia32_pause();
+            continue;
+        }
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+        if (++slices % 64 == 0) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(WT_E_HIP, "wt_decoder_stream_run: stream failed: %s", hipGetErrorString(q));
+            if (q == hipSuccess && slices > 4096) {
+                stream_scan_finished(e);
+                if (e->finished_seen >= e->submitted) break;
+                const unsigned long long m2 = __atomic_load_n(e->mailbox, __ATOMIC_ACQUIRE);
+                if (m2 == mb) return fail(WT_E_STATE, "wt_decoder_stream_run: idle stream, %d of %d utterances finished", e->finished_seen, e->submitted);
+            }
+        }
+    }
+    if (n_finished) *n_finished = e->finished_seen;
+    if (n_waiting) *n_waiting = e->submitted - e->admitted_seen;
+    if (n_steps) *n_steps = e->issued;
+    return WT_OK;
+}
+
+// Finished utterance `handle` (from wt_decoder_stream_submit): *len = its length (start token and EOS included), 0 while it is still
+// waiting or decoding (ids_out untouched).  With ids_out != NULL a finished utterance's ids are copied to HOST memory (capacity `cap`
+// >= max_length int32) and its cache row is released for the next submit.
+extern "C" int wt_decoder_stream_collect(wt_engine* e, int handle, int32_t* ids_out, int cap, int* len) {
+    if (!e || e->kind != WT_KIND_DECODER || !e->stream_mode) return fail(WT_E_STATE, "wt_decoder_stream_collect: no stream open");
+    if (handle < 0 || handle >= e->pool_rows || !len) return fail(WT_E_INVALID, "wt_decoder_stream_collect: bad handle %d", handle);
+    if (e->pool_state[handle] == 0) return fail(WT_E_STATE, "wt_decoder_stream_collect: row %d holds no utterance", handle);
+    const int n = __atomic_load_n(e->h_len + handle, __ATOMIC_ACQUIRE);
+    *len = n;
+    if (n == 0 || !ids_out) return WT_OK;
+    if (cap < n) return fail(WT_E_INVALID, "wt_decoder_stream_collect: %d ids, capacity %d", n, cap);
+    if (e->pool_state[handle] == 1) { e->pool_state[handle] = 2; e->finished_seen += 1; }
+    memcpy(ids_out, e->h_ids + (size_t)handle * e->max_length, (size_t)n * 4);   // row stride of stream_finish_kernel: this stream's max_length
+    e->pool_state[handle] = 0;
     return WT_OK;
 }
 
@@ -893,6 +1118,7 @@ extern "C" int wt_decoder_steps(wt_engine* e, int n_steps, void* stream) {
 extern "C" int wt_decoder_run(wt_engine* e, int lookahead, int* cur_len, int* n_unfinished, void* stream) {
     if (!e || e->kind != WT_KIND_DECODER) return fail(WT_E_INVALID, "wt_decoder_run: not a decoder engine");
     if (!e->begun) return fail(WT_E_STATE, "wt_decoder_run called before wt_decoder_begin");
+    if (e->stream_mode) return fail(WT_E_STATE, "wt_decoder_run: a continuous decode is open on this handle (wt_decoder_stream_run)");
     DeviceGuard guard(e->device);
     HIPCHK(guard.err);
     hipStream_t s = (hipStream_t)stream;
@@ -951,7 +1177,7 @@ extern "C" int wt_decoder_poll(wt_engine* e, int* cur_len, int* n_unfinished, in
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(e->h_state, e->st, sizeof(DecState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (cur_len) *cur_len = e->h_state->cur_len;
+    if (cur_len) *cur_len = e->h_state->cur_len[0];
     if (n_unfinished) *n_unfinished = e->h_state->n_unfinished;
     if (done) *done = e->h_state->done;
     for (EvTimer* t : {&e->t_cross, &e->t_gemm, &e->t_enc_attn, &e->t_skinny}) timer_collect(*t);
@@ -1043,7 +1269,7 @@ extern "C" int wt_engine_run(wt_engine* e, const wt_binding* in, int n_in, const
     LAUNCH(launch_set_state(e->st, /*cur_len=*/1, /*pos=*/e->c_ms - 1, /*self_len=*/cache_len, s));
     StepIO io;
     io.ids = data; io.ids_ld = 1; io.self_k = nsk; io.self_v = nsv; io.self_cap = cache_len + 1;
-    io.cross_k = nck; io.cross_v = ncv; io.logits = logits; io.B = 1; io.kv_esz = 4;
+    io.cross_k = nck; io.cross_v = ncv; io.cross_rows = 1; io.slot_row = nullptr; io.logits = logits; io.B = 1; io.kv_esz = 4;
     io.nsplit_self = 1; io.nsplit_cross = pick_splits(1, e->H, S);
     io.alive = nullptr;
     io.embed = true;
@@ -1059,7 +1285,11 @@ static int replay_and_time(hipGraph_t g, int iters, int launches_per_replay, flo
     hipGraphExec_t ge = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     float ms = 0.f;
-    hipError_t he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipError_t he;
+    {
+        std::lock_guard<std::mutex> lock(g_capture_mutex);
+        he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    }
     if (he == hipSuccess) he = hipEventCreate(&a);
     if (he == hipSuccess) he = hipEventCreate(&b);
     if (he == hipSuccess) he = hipGraphLaunch(ge, s);  // warm-up replay (replayed on the caller's stream, like the decode step)
@@ -1101,22 +1331,25 @@ extern "C" int wt_decoder_time_kernel(wt_engine* e, const char* which, int iters
     hipStream_t s = (hipStream_t)stream;
     StepIO io;
     io.ids = e->ids; io.ids_ld = e->max_length; io.self_k = e->self_k; io.self_v = e->self_v; io.self_cap = e->T;
-    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
+    io.cross_k = e->cross_k; io.cross_v = e->cross_v; io.cross_rows = e->cross_rows; io.logits = e->logits; io.B = e->B; io.kv_esz = e->kv_esz;
     io.nsplit_self = e->nsplit_self; io.nsplit_cross = e->nsplit_cross; io.embed = false; io.argmax = nullptr; io.argmax_parts = nullptr;
-    io.alive = nullptr;
+    io.alive = nullptr; io.slot_row = nullptr;
     struct ProfilingOff {   // no event records inside the capture; the caller's setting comes back on every exit path
         wt_engine* e; bool was;
         explicit ProfilingOff(wt_engine* e_) : e(e_), was(e_->profiling) { e->profiling = false; }
         ~ProfilingOff() { e->profiling = was; }
     } profiling_off(e);
     hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
-    int rc = WT_OK;
-    for (int i = 0; i < e->L && rc == WT_OK; ++i) rc = enqueue_layer_part(e, io, i, e->dh, e->dh2, part, e->own_stream);
-    hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
-    if (rc != WT_OK || ce != hipSuccess) {
-        if (g) hipGraphDestroy(g);
-        return fail(WT_E_HIP, "capturing the timing graph of '%s' failed", which);
+    {   // captures / instantiations are serialised process-wide (enqueue_steps)
+        std::lock_guard<std::mutex> lock(g_capture_mutex);
+        HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+        int rc = WT_OK;
+        for (int i = 0; i < e->L && rc == WT_OK; ++i) rc = enqueue_layer_part(e, io, i, e->dh, e->dh2, part, e->own_stream);
+        hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
+        if (rc != WT_OK || ce != hipSuccess) {
+            if (g) hipGraphDestroy(g);
+            return fail(WT_E_HIP, "capturing the timing graph of '%s' failed", which);
+        }
     }
     return replay_and_time(g, iters, e->L, avg_us, s);
 }

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int* __restrict__ 
                                                         const float* __restrict__ pos_emb, float* __restrict__ x, int d,
                                                         const DecState* __restrict__ st, int emb_half) {
     const int b = blockIdx.x;
-    const int tok = ids[(size_t)b * ids_ld + st->cur_len - 1];
-    const float4* pe = reinterpret_cast<const float4*>(pos_emb + (size_t)st->pos * d);
+    const int tok = ids[(size_t)b * ids_ld + st->cur_len[b] - 1];
+    const float4* pe = reinterpret_cast<const float4*>(pos_emb + (size_t)st->pos[b] * d);
     float4* xo = reinterpret_cast<float4*>(x + (size_t)b * d);
     for (int i = threadIdx.x; i < (d >> 2); i += 256) {
         const float4 a = load_emb4(tok_emb, (size_t)tok * d + 4 * i, emb_half != 0), c = pe[i];
@@ -155,7 +155,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
         if (p.ymode == YMODE_PLAIN) {
             if (p.resid) resid_pf = p.resid[(size_t)b_pf * p.N + n_pf];
         } else if (!ARGMAX && p.ymode == YMODE_QKV_APPEND) {
-            self_len_pf = p.st->self_len;
+            self_len_pf = p.st->self_len[b_pf];
         }
     }
 
@@ -326,7 +326,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
     float* am_tr = nullptr;
     if constexpr (ARGMAX) {
         am_mk[0] = p.am_mask[min(row_begin + my_r, p.N - 1)];
-        am_at_begin = p.st->cur_len == p.am_begin_index;
+        am_at_begin = p.st->cur_len[min(my_b, p.B - 1)] == p.am_begin_index;
         // raw-logits trace row of this step; steps enqueued past the stop test (st->done) or past the trace's last row must not write
         if (p.am_trace && !p.st->done && p.st->step < p.am_trace_steps)
             am_tr = p.am_trace + ((size_t)min(my_b, p.B - 1) * p.am_trace_steps + p.st->step) * p.N;
@@ -628,7 +628,8 @@ __device__ __forceinline__ float row8_allreduce_sum(float v) {   // sum over eac
 // NTHR = 512: eight waves per block = twice the streams, half the dependent load -> consume round trips per stream and twice the bytes
 // in flight per CU (the kernel is bound by round trips x bytes in flight, not by the HBM rate: it takes 17.1 us with a layer's K/V
 // resident in the Infinity Cache and 17.8 from HBM).
-template <int U, bool NT, bool KVH, bool PIPE = false, bool ALIVE = false, int NTHR = 256>
+// SLOT (continuous mode, cross attention): slot b's keys / values live in cache row slot_row[b] of a pool, not in row b.
+template <int U, bool NT, bool KVH, bool PIPE = false, bool ALIVE = false, int NTHR = 256, bool SLOT = false>
 __global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
     constexpr int LPK = KVH ? 8 : 16;          // lanes per key
     constexpr int DPL = HEAD_DIM / LPK;        // head dims per lane: 8 or 4 (16 bytes of K or V either way)
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & (LPK - 1), sid = tid / LPK;
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int len = p.fixed_len > 0 ? p.fixed_len : p.st->self_len + 1;
+    const int len = p.fixed_len > 0 ? p.fixed_len : p.st->self_len[b] + 1;
     const int chunk = (len + p.n_split - 1) / p.n_split;
     const int s_begin = split * chunk, s_end = min(len, s_begin + chunk);
     const int d = p.H * HEAD_DIM;
@@ -651,8 +652,9 @@ __global__ __launch_bounds__(NTHR) void dec_attn_kernel(const DecAttnParams p) {
     const int nstr = (NTHR == 256 || nkeys >= 128) ? NSTR : NSTR / 2;
     if (NTHR != 256 && sid >= nstr) return;   // wave-uniform (LPK divides 64)
 
-    const char* kb = reinterpret_cast<const char*>(p.kcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
-    const char* vb = reinterpret_cast<const char*>(p.vcache) + (((size_t)b * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
+    const int crow = SLOT ? max(p.slot_row[b], 0) : b;   // (an idle slot reads row 0: finite values nobody uses)
+    const char* kb = reinterpret_cast<const char*>(p.kcache) + (((size_t)crow * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
+    const char* vb = reinterpret_cast<const char*>(p.vcache) + (((size_t)crow * p.H + h) * p.s_cap * HEAD_DIM + DPL * c) * KSZ;
     typedef float f4v __attribute__((ext_vector_type(4)));   // 16 raw bytes
     auto load_tile = [&](f4v (&kk)[U], f4v (&vv)[U], const int s0) {
 #pragma unroll
@@ -917,6 +919,18 @@ hipError_t launch_dec_attn(const DecAttnParams& p, hipStream_t s) {
     // (sixteen-wave blocks measured SLOWER than eight: cross-attention 19.2 -> 20.6 us, self-attention at 224 keys 5.9 -> 6.4)
     // (and four keys per stream and iteration stay best in the eight-wave form: U = 2 / 4 / 8 -> 19.9 / 19.8 / 20.1 us cross-attention,
     //  6.3 / 5.8 / 6.0 us self-attention at 224 keys)
+    if (p.slot_row) {   // continuous mode: the cross-attention launches of the step graph (the engine's own plans only)
+        if (!p.kv_half) {
+            if (p.alive && nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, true, 512, true>), grid, dim3(512), 0, s, p);
+            else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, false, 512, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((dec_attn_kernel<4, false, false, false, false, 512, true>), grid, dim3(512), 0, s, p);
+        } else {
+            if (p.alive && nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true, true, 256, true>), grid, dim3(256), 0, s, p);
+            else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, true, true, false, 256, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((dec_attn_kernel<4, false, true, false, false, 256, true>), grid, dim3(256), 0, s, p);
+        }
+        return hipGetLastError();
+    }
     if (threads == 512 && !p.kv_half && pipe != 1) {
         if (p.alive && nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, true, 512>), grid, dim3(512), 0, s, p);
         else if (nt) hipLaunchKernelGGL((dec_attn_kernel<4, true, false, false, false, 512>), grid, dim3(512), 0, s, p);
@@ -954,7 +968,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
     __shared__ int s_idx[4];
     const DecState* st = p.st;
     if (st->done) return;  // steps enqueued past the stop test are no-ops
-    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y, cur_len = st->cur_len, step = st->step;
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y, cur_len = st->cur_len[b], step = st->step;
     const bool at_begin = cur_len == p.begin_index;
     const float* lg = p.logits + (size_t)b * p.V;
     float* tr = p.trace ? p.trace + ((size_t)b * (p.max_length - 1) + step) * p.V : nullptr;
@@ -1017,133 +1031,293 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const SelectParams p
     }
 }
 
-__global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p) {
-    __shared__ int s_tok[16];
-    __shared__ int s_pos;
-    __shared__ int s_unf[16];
-    DecState* st = p.st;
-    const int tid = threadIdx.x;
-    // final masked argmax of every row over its n_parts partial results (lowest index on ties).  All rows at once: a group of
-    // `lpb` lanes per row (32 at B <= 8, 16 at B <= 16), every load of the block in flight together -- the partials were written by
-    // other XCDs a kernel ago, so this is one memory round trip; row by row it was B of them (measured 14 us per step at B = 8).
-    // The candidates do not depend on DecState: the first 8 x lpb of a row are requested BEFORE it is read (one dependent round
-    // trip fewer), by unconditional clamped loads.
-    const int lpb = p.B <= 4 ? 64 : p.B <= 8 ? 32 : 16;
-    const int b = tid / lpb, l = tid % lpb;
-    const size_t pbase = (size_t)min(b, p.B - 1) * p.n_parts;
+// Final masked argmax of every row over its n_parts partial results (lowest index on ties), shared by the two finish kernels.  All rows
+// at once: a group of `lpb` lanes per row (64 at B <= 4, 32 at B <= 8, 16 at B <= 16), every load of the block in flight together -- the
+// partials were written by other XCDs a kernel ago, so this is one memory round trip; row by row it was B of them (measured 14 us per
+// step at B = 8).  The candidates do not depend on DecState: the first 8 x lpb of a row are requested BEFORE it is read (one dependent
+// round trip fewer), by unconditional clamped loads -- `finish_request` / `finish_argmax` are the two halves.
+struct FinishCand {
     float pv[8];
     int pi[8];
+};
+__device__ __forceinline__ void finish_request(const SelectParams& p, const int b, const int l, const int lpb, FinishCand& c) {
+    const size_t pbase = (size_t)min(b, p.B - 1) * p.n_parts;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = min(l + k * lpb, p.n_parts - 1);
-        pv[k] = p.part_val[pbase + i];
-        pi[k] = p.part_idx[pbase + i];
+        c.pv[k] = p.part_val[pbase + i];
+        c.pi[k] = p.part_idx[pbase + i];
     }
-    const int unf = p.unfinished[min(b, p.B - 1)];
-    const int done = st->done, cur_len = st->cur_len, step = st->step;
-    if (done) {         // block-uniform: steps enqueued past the stop test are no-ops (the host still sees them retire)
-        if (tid == 0) {
-            const int seq = st->seq + 1;
-            st->seq = seq;
-            unsigned unf_mask = 0;   // unchanged since the stop: the host may read this word instead of the stopping step's
-            for (int r = 0; r < p.B; ++r) unf_mask |= p.unfinished[r] ? 1u << r : 0u;
-            if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, 1, cur_len, unf_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
-    {
-        const int forced = p.forced[cur_len];                          // ForceTokensLogitsProcessor
-        float best = -INFINITY;
-        int bidx = 0x7fffffff;
-        if (b < p.B) {
+}
+__device__ __forceinline__ int finish_argmax(const SelectParams& p, const int b, const int l, const int lpb, const FinishCand& c) {
+    const size_t pbase = (size_t)min(b, p.B - 1) * p.n_parts;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    if (b < p.B) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (l + k * lpb < p.n_parts && argmax_better(pv[k], pi[k], best, bidx)) {
-                    best = pv[k];
-                    bidx = pi[k];
-                }
-            for (int i = l + 8 * lpb; i < p.n_parts; i += lpb) {
-                const float v = p.part_val[pbase + i];
-                const int ix = p.part_idx[pbase + i];
-                if (argmax_better(v, ix, best, bidx)) {
-                    best = v;
-                    bidx = ix;
-                }
+        for (int k = 0; k < 8; ++k)
+            if (l + k * lpb < p.n_parts && argmax_better(c.pv[k], c.pi[k], best, bidx)) {
+                best = c.pv[k];
+                bidx = c.pi[k];
             }
-        }
-        for (int o = lpb >> 1; o >= 1; o >>= 1) {   // lpb <= 64 and a power of two: a group never straddles a wave
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bidx, o);
-            if (argmax_better(ov, oi, best, bidx)) {
-                best = ov;
-                bidx = oi;
+        for (int i = l + 8 * lpb; i < p.n_parts; i += lpb) {
+            const float v = p.part_val[pbase + i];
+            const int ix = p.part_idx[pbase + i];
+            if (argmax_better(v, ix, best, bidx)) {
+                best = v;
+                bidx = ix;
             }
-        }
-        if (b < p.B && l == 0) {
-            int tok = bidx;
-            if ((unsigned)tok >= (unsigned)p.V) tok = p.eos;      // unreachable with a NaN-aware argmax; never index the embedding out of range
-            if (forced >= 0) tok = forced;
-            if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
-            if (p.force_eos_rows && step == p.force_eos_rows[b]) tok = p.eos;    // ... per row (variable-length workload)
-            if (!unf) tok = p.pad;                                 // finished rows keep emitting pad
-            p.ids[(size_t)b * p.max_length + cur_len] = tok;
-            if (tok == p.eos) p.unfinished[b] = 0;
-            s_tok[b] = tok;
-            s_unf[b] = (tok == p.eos) ? 0 : unf;
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        int nu = 0;
-        unsigned unf_mask = 0;
-        for (int b = 0; b < p.B; ++b)
-            if (s_unf[b]) {
-                ++nu;
-                unf_mask |= 1u << b;
-            }
-        st->n_unfinished = nu;
-        st->cur_len = cur_len + 1;
-        st->pos += 1;
-        st->self_len += 1;
-        st->step = step + 1;
-        const int now_done = nu == 0 || cur_len + 1 >= p.max_length;   // run.py:219-226
-        if (now_done) st->done = 1;
-        const int seq = st->seq + 1;
-        st->seq = seq;
-        s_pos = st->pos;
-        // progress report for wt_decoder_run: one self-contained 64-bit word, written through to the pinned host page (the ids
-        // themselves are fetched later by a stream-ordered copy, so no release fence -- and no L2 write-back -- is needed here)
-        if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, now_done, cur_len + 1, unf_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int o = lpb >> 1; o >= 1; o >>= 1) {   // lpb <= 64 and a power of two: a group never straddles a wave
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (argmax_better(ov, oi, best, bidx)) {
+            best = ov;
+            bidx = oi;
+        }
     }
-    __syncthreads();
-    if (!p.next_x || cur_len + 1 >= p.max_length) return;
-    // input of the next step: x[b] = embed_tokens[tok_b] + embed_positions[pos]   (model.py:423-425)
+    if ((unsigned)bidx >= (unsigned)p.V) bidx = p.eos;   // unreachable with a NaN-aware argmax; never index the embedding out of range
+    return bidx;
+}
+// input of the next step for every row: x[b] = embed_tokens[tok_b] + embed_positions[pos_b]   (model.py:423-425)
+__device__ __forceinline__ void finish_embed(const SelectParams& p, const int* s_tok, const int* s_pos, const int tid) {
     const int d4 = p.d_model >> 2;
-    const float4* pe = reinterpret_cast<const float4*>(p.pos_emb + (size_t)s_pos * p.d_model);
     for (int i = tid; i < p.B * d4; i += 256) {
         const int b = i / d4, c = i - b * d4;
-        const float4 a = load_emb4(p.tok_emb, (size_t)s_tok[b] * p.d_model + 4 * c, p.emb_half != 0), q = pe[c];
+        const float4 a = load_emb4(p.tok_emb, (size_t)s_tok[b] * p.d_model + 4 * c, p.emb_half != 0);
+        const float4 q = reinterpret_cast<const float4*>(p.pos_emb + (size_t)s_pos[b] * p.d_model)[c];
         reinterpret_cast<float4*>(p.next_x + (size_t)b * p.d_model)[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
     }
 }
+
+__global__ __launch_bounds__(256) void greedy_finish_kernel(const SelectParams p) {
+    __shared__ int s_tok[MAX_ROWS];
+    __shared__ int s_pos[MAX_ROWS];
+    __shared__ int s_unf[MAX_ROWS];
+    DecState* st = p.st;
+    const int tid = threadIdx.x;
+    const int lpb = p.B <= 4 ? 64 : p.B <= 8 ? 32 : 16;
+    const int b = tid / lpb, l = tid % lpb, bc = min(b, p.B - 1);
+    FinishCand cand;
+    finish_request(p, b, l, lpb, cand);
+    const int unf = p.unfinished[bc];
+    // the rows of a wt_decoder_begin batch stay aligned: row 0's counters are everybody's
+    const int done = st->done, cur_len = st->cur_len[0], step = st->step, pos = st->pos[0], self_len = st->self_len[0], seq = st->seq + 1,
+              epoch = st->epoch;
+    if (done) {         // block-uniform: steps enqueued past the stop test are no-ops (the host still sees them retire)
+        if (tid == 0) {
+            st->seq = seq;
+            unsigned unf_mask = 0;   // unchanged since the stop: the host may read this word instead of the stopping step's
+            for (int r = 0; r < p.B; ++r) unf_mask |= p.unfinished[r] ? 1u << r : 0u;
+            if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(epoch, seq, 1, cur_len, unf_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int forced = p.forced[cur_len];                          // ForceTokensLogitsProcessor
+    const int row_eos = p.force_eos_rows ? p.force_eos_rows[bc] : -1;
+    int tok = finish_argmax(p, b, l, lpb, cand);
+    if (b < p.B && l == 0) {
+        if (forced >= 0) tok = forced;
+        if (p.force_eos_step >= 0 && step == p.force_eos_step) tok = p.eos;  // bench-only transcript length
+        if (row_eos >= 0 && step == row_eos) tok = p.eos;                    // ... per row (variable-length workload)
+        if (!unf) tok = p.pad;                                 // finished rows keep emitting pad
+        p.ids[(size_t)b * p.max_length + cur_len] = tok;
+        if (tok == p.eos) p.unfinished[b] = 0;
+        s_tok[b] = tok;
+        s_pos[b] = pos + 1;
+        s_unf[b] = (tok == p.eos) ? 0 : unf;
+    }
+    __syncthreads();   // (every thread has read the counters above before any of them is advanced)
+    if (tid < p.B) {
+        st->cur_len[tid] = cur_len + 1;
+        st->pos[tid] = pos + 1;
+        st->self_len[tid] = self_len + 1;
+    }
+    if (tid == 0) {
+        int nu = 0;
+        unsigned unf_mask = 0;
+        for (int r = 0; r < p.B; ++r)
+            if (s_unf[r]) {
+                ++nu;
+                unf_mask |= 1u << r;
+            }
+        st->n_unfinished = nu;
+        st->step = step + 1;
+        const int now_done = nu == 0 || cur_len + 1 >= p.max_length;   // run.py:219-226
+        if (now_done) st->done = 1;
+        st->seq = seq;
+        // progress report for wt_decoder_run: one self-contained 64-bit word, written through to the pinned host page (the ids
+        // themselves are fetched later by a stream-ordered copy, so no release fence -- and no L2 write-back -- is needed here)
+        if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(epoch, seq, now_done, cur_len + 1, unf_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!p.next_x || cur_len + 1 >= p.max_length) return;
+    finish_embed(p, s_tok, s_pos, tid);
+}
+
+// ---- continuous mode (wt_decoder_stream_*): every slot at its own position; a row that stops is replaced AT ONCE, by this kernel, with
+// the next utterance of the waiting queue (its cross K/V were projected into a pool row beforehand): no step is spent on a finished
+// row and no host round trip sits between an EOS and the next utterance's first token.  The reference gets per-utterance stopping from
+// decoding one clip at a time (run.py:219-226); here the batch stays full instead.
+// Host visibility: every token of an active slot also goes to the pinned id row of its pool row, and a stopping row publishes its final
+// length there behind a system-scope fence -- the host never copies ids from the device in this mode.
+__device__ __forceinline__ bool stream_admit(const SelectParams& p, DecState* st, const int b, int* s_tok, int* s_pos) {
+    const int head = st->q_head;
+    if (head >= st->q_tail) {   // nothing waiting: the slot idles (pad at its frozen position: finite, unused)
+        st->slot_row[b] = -1;
+        p.unfinished[b] = 0;
+        s_tok[b] = p.pad;
+        s_pos[b] = 0;
+        return false;
+    }
+    const int r = st->queue[head % STREAM_QCAP];
+    st->q_head = head + 1;
+    st->slot_row[b] = r;
+    st->cur_len[b] = 1;
+    st->pos[b] = 0;
+    st->self_len[b] = 0;
+    st->row_force[b] = st->rec_force[r];
+    p.unfinished[b] = 1;
+    p.ids[(size_t)b * p.max_length] = p.start_token;
+    __hip_atomic_store(p.host_ids + (size_t)r * p.max_length, p.start_token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_tok[b] = p.start_token;
+    s_pos[b] = 0;
+    return true;
+}
+__device__ __forceinline__ void stream_report(const SelectParams& p, DecState* st, const int seq) {   // thread 0, after the admissions
+    int na = 0;
+    unsigned mask = 0;
+    for (int r = 0; r < p.B; ++r)
+        if (st->slot_row[r] >= 0) {
+            ++na;
+            mask |= 1u << r;
+        }
+    st->n_unfinished = na;
+    st->done = na == 0;
+    st->seq = seq;
+    if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, na == 0, st->q_head & 0x7fff, mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void stream_finish_kernel(const SelectParams p) {
+    __shared__ int s_tok[MAX_ROWS];
+    __shared__ int s_pos[MAX_ROWS];
+    __shared__ int s_fin[MAX_ROWS];
+    DecState* st = p.st;
+    const int tid = threadIdx.x;
+    const int lpb = p.B <= 4 ? 64 : p.B <= 8 ? 32 : 16;
+    const int b = tid / lpb, l = tid % lpb, bc = min(b, p.B - 1);
+    FinishCand cand;
+    finish_request(p, b, l, lpb, cand);
+    const int row = st->slot_row[bc], cur_len = st->cur_len[bc], pos = st->pos[bc], eos_at = st->row_force[bc];
+    const int done = st->done, seq = st->seq + 1;
+    if (done) {   // block-uniform: nothing active, nothing waiting -- a surplus step behind the last utterance
+        if (tid == 0) {
+            st->seq = seq;
+            if (p.mailbox) __hip_atomic_store(p.mailbox, mailbox_word(st->epoch, seq, 1, st->q_head & 0x7fff, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int forced = p.forced[min(cur_len, p.max_length)];
+    int tok = finish_argmax(p, b, l, lpb, cand);
+    if (b < p.B && l == 0) {
+        int fin = 0;
+        if (row >= 0) {
+            if (forced >= 0) tok = forced;
+            if (eos_at >= 0 && cur_len - 1 == eos_at) tok = p.eos;   // bench only: this utterance's transcript length
+            p.ids[(size_t)b * p.max_length + cur_len] = tok;
+            __hip_atomic_store(p.host_ids + (size_t)row * p.max_length + cur_len, tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            fin = tok == p.eos || cur_len + 1 >= p.max_length;        // this utterance's own stop test (run.py:219-226 at batch 1)
+            if (fin) {   // release: every id of the row (this thread's own stores, this step's and the earlier kernels') is in host memory
+                         // before its length says so
+                __hip_atomic_store(p.host_len + row, cur_len + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                st->cur_len[b] = cur_len + 1;
+                st->pos[b] = pos + 1;
+                st->self_len[b] = pos + 1;
+                s_tok[b] = tok;
+                s_pos[b] = pos + 1;
+            }
+        }
+        s_fin[b] = fin || row < 0;   // stopped just now, or idle: both take the next waiting utterance if there is one
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int r = 0; r < p.B; ++r)
+            if (s_fin[r]) stream_admit(p, st, r, s_tok, s_pos);
+        st->step += 1;
+        stream_report(p, st, seq);
+    }
+    __syncthreads();
+    if (!p.next_x) return;
+    finish_embed(p, s_tok, s_pos, tid);
+}
+
+// host -> device hand-over of prepared utterances (stream-ordered behind their cross-K/V projection): append to the waiting queue,
+// then fill idle slots directly -- so a decode that had drained (or has not started) begins without a wasted step
+__global__ __launch_bounds__(256) void stream_publish_kernel(const SelectParams p, const StreamPublish pub) {
+    __shared__ int s_tok[MAX_ROWS];
+    __shared__ int s_pos[MAX_ROWS];
+    __shared__ int s_new[MAX_ROWS];
+    DecState* st = p.st;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int tail = st->q_tail;
+        for (int i = 0; i < pub.n; ++i) {
+            st->queue[tail % STREAM_QCAP] = pub.rows[i];
+            st->rec_force[pub.rows[i]] = pub.force[i];
+            ++tail;
+        }
+        st->q_tail = tail;
+        for (int r = 0; r < p.B; ++r) s_new[r] = st->slot_row[r] < 0 ? (stream_admit(p, st, r, s_tok, s_pos) ? 1 : 0) : 0;
+        int na = 0;
+        for (int r = 0; r < p.B; ++r) na += st->slot_row[r] >= 0;
+        st->n_unfinished = na;
+        st->done = na == 0;
+    }
+    __syncthreads();
+    // the first input of the admitted slots (the others keep the input their last step left)
+    const int d4 = p.d_model >> 2;
+    for (int i = tid; i < p.B * d4; i += 256) {
+        const int b = i / d4, c = i - b * d4;
+        if (!s_new[b]) continue;
+        const float4 a = load_emb4(p.tok_emb, (size_t)s_tok[b] * p.d_model + 4 * c, p.emb_half != 0);
+        const float4 q = reinterpret_cast<const float4*>(p.pos_emb + (size_t)s_pos[b] * p.d_model)[c];
+        reinterpret_cast<float4*>(p.next_x + (size_t)b * p.d_model)[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+    }
+}
+hipError_t launch_stream_publish(const SelectParams& p, const StreamPublish& pub, hipStream_t s) {
+    if (p.B < 1 || p.B > MAX_ROWS || pub.n < 0 || pub.n > MAX_ROWS || !p.host_ids || !p.host_len || !p.next_x) return hipErrorInvalidValue;
+    for (int i = 0; i < pub.n; ++i)
+        if (pub.rows[i] < 0 || pub.rows[i] >= STREAM_QCAP) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stream_publish_kernel, dim3(1), dim3(256), 0, s, p, pub);
+    return hipGetLastError();
+}
+
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s) {
-    if (p.B > 16 || p.n_parts < 1 || (!p.fused && p.n_parts != SELECT_CHUNKS)) return hipErrorInvalidValue;
+    if (p.B > MAX_ROWS || p.n_parts < 1 || (!p.fused && p.n_parts != SELECT_CHUNKS)) return hipErrorInvalidValue;
+    if (p.stream && (!p.host_ids || !p.host_len || p.trace)) return hipErrorInvalidValue;
     if (!p.fused) hipLaunchKernelGGL(greedy_select_kernel, dim3(SELECT_CHUNKS, p.B), dim3(256), 0, s, p);  // else: done by the vocabulary GEMV
-    hipLaunchKernelGGL(greedy_finish_kernel, dim3(1), dim3(256), 0, s, p);
+    if (p.stream) hipLaunchKernelGGL(stream_finish_kernel, dim3(1), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(greedy_finish_kernel, dim3(1), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
 __global__ void dec_init_kernel(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, int epoch) {
     const int t = threadIdx.x;
     if (t == 0) {
-        st->cur_len = 1;
-        st->pos = 0;
-        st->self_len = 0;
         st->done = max_length <= 1 ? 1 : 0;
         st->n_unfinished = B;
         st->step = 0;
         st->seq = 0;
         st->epoch = epoch;
+        st->q_head = st->q_tail = 0;
+    }
+    if (t < MAX_ROWS) {
+        st->cur_len[t] = 1;
+        st->pos[t] = 0;
+        st->self_len[t] = 0;
+        st->slot_row[t] = t;
+        st->row_force[t] = -1;
     }
     for (int b = t; b < B; b += blockDim.x) {
         ids[(size_t)b * max_length] = start_token;
@@ -1155,10 +1329,35 @@ hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int m
     return hipGetLastError();
 }
 
+__global__ void stream_init_kernel(DecState* st, int* unfinished, int B, int epoch) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        st->done = 1;            // drained until the first publish
+        st->n_unfinished = 0;
+        st->step = 0;
+        st->seq = 0;
+        st->epoch = epoch;
+        st->q_head = st->q_tail = 0;
+    }
+    if (t < MAX_ROWS) {
+        st->cur_len[t] = 1;
+        st->pos[t] = 0;
+        st->self_len[t] = 0;
+        st->slot_row[t] = -1;
+        st->row_force[t] = -1;
+        if (t < B) unfinished[t] = 0;
+    }
+}
+hipError_t launch_stream_init(DecState* st, int* unfinished, int B, int epoch, hipStream_t s) {
+    hipLaunchKernelGGL(stream_init_kernel, dim3(1), dim3(64), 0, s, st, unfinished, B, epoch);
+    return hipGetLastError();
+}
+
 __global__ void set_state_kernel(DecState* st, int cur_len, int pos, int self_len) {
-    st->cur_len = cur_len;
-    st->pos = pos;
-    st->self_len = self_len;
+    st->cur_len[0] = cur_len;
+    st->pos[0] = pos;
+    st->self_len[0] = self_len;
+    st->slot_row[0] = 0;
     st->done = 0;
     st->n_unfinished = 1;
     st->step = 0;

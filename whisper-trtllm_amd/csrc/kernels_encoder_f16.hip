@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_dma5_kernel(const GemmParams 
 hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, int force_variant) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
     if ((p.K & 7) || (p.lda & 7) || (p.a_batch_stride & 7)) return hipErrorInvalidValue;
+    if (p.a_rows_per_batch < 1 || p.c_rows_per_batch < 1) return hipErrorInvalidValue;   // divisors of the row maps below (as launch_gemm_f32 checks)
     const bool kv = p.epi == EPI_KV_HEADS;   // cross-K/V projection of an fp16 decoder engine: 128x128 kernels only (generic epilogues)
     if (kv && (p.N != 2 * p.kv_heads * HEAD_DIM || !p.C2 || p.resid || p.pos || p.act || (reinterpret_cast<uintptr_t>(p.C) & 15) ||
                (reinterpret_cast<uintptr_t>(p.C2) & 15) || (reinterpret_cast<uintptr_t>(p.bias) & 15)))

@@ -12,15 +12,27 @@ namespace wt {
 
 // ---- device-resident decode state: every per-step quantity kernels need lives here so that one captured
 // hipGraph replays for every step (nothing step-dependent is baked into kernel arguments) ------------------
+// The per-ROW quantities are arrays over the decode slots: a batch started by wt_decoder_begin keeps its rows aligned (all entries
+// equal), the continuous mode (wt_decoder_stream_*) refills a slot with the next waiting utterance the moment its row stops, so every
+// slot runs at its own position -- what the reference's one-clip-at-a-time loop gives for free (run.py:219-226, cal_wer.py:249-287).
+constexpr int MAX_ROWS = 16;       // decode slots per engine call
+constexpr int STREAM_QCAP = 256;   // continuous mode: ring of waiting utterances, and the largest cross-cache pool (rows)
 struct DecState {
-    int cur_len;       // tokens in each row of `ids` so far (prompt included)
-    int pos;           // decoder position of the token being fed == number of cached self keys
-    int self_len;      // valid keys already in the self cache; the new key/value row is written at this index
-    int done;          // stop test fired (all rows EOS, or cur_len >= max_length)
-    int n_unfinished;  // rows that have not produced EOS yet
+    int done;          // stop test fired (all rows EOS, or cur_len >= max_length); continuous mode: no slot active and nothing waiting
+    int n_unfinished;  // rows that have not produced EOS yet (continuous mode: active slots)
     int step;          // 0-based count of executed steps
     int seq;           // greedy_finish launches since wt_decoder_begin, no-op ones included (the host mailbox's progress counter)
     int epoch;         // which wt_decoder_begin this state belongs to (low 16 bits travel in the mailbox word)
+    int q_head;        // continuous mode: utterances admitted to a slot so far (device-owned) ...
+    int q_tail;        // ... of those published by the host (stream_publish_kernel)
+    int pad0;
+    int cur_len[MAX_ROWS];    // tokens in row b of `ids` so far (prompt included)
+    int pos[MAX_ROWS];        // decoder position of the token being fed to row b
+    int self_len[MAX_ROWS];   // valid keys already in row b's self cache; the new key/value row is written at this index
+    int slot_row[MAX_ROWS];   // continuous mode: cross-cache pool row of the utterance in slot b, -1 = idle slot
+    int row_force[MAX_ROWS];  // continuous mode, bench only: row-local 0-based step at which slot b's utterance emits EOS, -1 = never
+    int queue[STREAM_QCAP];       // continuous mode: pool rows waiting for a slot, entry i at queue[i % STREAM_QCAP]
+    int rec_force[STREAM_QCAP];   // continuous mode: row_force of the utterance in pool row r
 };
 
 // Host mailbox word (64 bits, written by greedy_finish_kernel with ONE system-scope store into pinned host memory after every
@@ -112,6 +124,7 @@ struct DecAttnParams {
     int kv_half;           // kcache / vcache are IEEE half (fp16 decoder engines keep their RESIDENT caches in fp16; fp32 arithmetic)
     const int* alive;      // optional [B]: rows with alive[b] == 0 (finished: they emit pad whatever their logits) stream no K/V; their
                            // context / partials keep the previous step's (finite) values.  nullptr: every row attends.
+    const int* slot_row;   // optional [B] (continuous mode, cross attention): slot b reads cache row max(slot_row[b], 0) instead of row b
 };
 
 // A/B tuning switches (WT_NSPLIT_CROSS, WT_GEMM_NO_DMA, ...; DESIGN.md "Tuning knobs") are lab tools, not part of the C-ABI's
@@ -193,9 +206,22 @@ struct SelectParams {
     int emb_half;          // tok_emb is IEEE half (fp16 decoder engines)
     const int* force_eos_rows;       // optional [B]: row b emits EOS at 0-based step force_eos_rows[b] (< 0: never) -- bench-only transcript lengths
     unsigned long long* mailbox;     // optional: device address of the engine's pinned host mailbox (mailbox_word above)
+    // continuous mode (stream != 0): finished utterances report to the host through pinned memory, indexed by cross-cache pool row
+    int stream, start_token;
+    int* host_ids;                   // device address of the pinned id rows [pool][max_length]
+    int* host_len;                   // device address of the pinned final lengths [pool] (0 = still decoding)
 };
 hipError_t launch_greedy_select(const SelectParams& p, hipStream_t s);
 hipError_t launch_dec_init(DecState* st, int* ids, int* unfinished, int B, int max_length, int start_token, int epoch, hipStream_t s);
+// continuous mode: empty slots, empty queue
+hipError_t launch_stream_init(DecState* st, int* unfinished, int B, int epoch, hipStream_t s);
+// continuous mode: append `n` prepared utterances (cross-cache pool rows, forced-EOS steps) to the waiting queue and admit into idle slots
+struct StreamPublish {
+    int n;
+    int rows[MAX_ROWS];
+    int force[MAX_ROWS];
+};
+hipError_t launch_stream_publish(const SelectParams& p, const StreamPublish& pub, hipStream_t s);
 hipError_t launch_copy_cache_rows(const float* src, float* dst, int LH, int src_rows, int dst_rows, int n_rows,
                                   hipStream_t s);
 hipError_t launch_set_state(DecState* st, int cur_len, int pos, int self_len, hipStream_t s);

@@ -13,6 +13,24 @@ from . import _lib
 from .logger import logger
 
 
+def under_rocprof() -> bool:
+    """True when rocprofv3's tool library is loaded into this process (it is LD_PRELOADed by the `rocprofv3` launcher and intercepts every
+    HIP / HSA call, incl. the AQL packets of a hipGraph replay).  A 4-worker `WhisperPipeline` run under `rocprofv3 --kernel-trace`
+    aborted with SIGSEGV in round 3: the faulting frame lies in a module mapped at process start (where the preloaded profiler
+    libraries live), below hipGraphLaunch <- enqueue_steps <- wt_decoder_run of a worker thread; the frames could not be symbolised
+    (DESIGN.md "The four-worker abort under rocprofv3").  The same runs without the profiler are clean (soak, test suite, driver bench),
+    so the hazard is several host threads replaying graphs at once UNDER THE PROFILER -- `WhisperPipeline` therefore runs one worker then."""
+    import os
+    env = os.environ
+    if "rocprofiler" in env.get("LD_PRELOAD", "") or env.get("ROCP_TOOL_LIBRARIES") or any(k.startswith("ROCPROF_") for k in env):
+        return True
+    try:
+        with open("/proc/self/maps") as f:
+            return any("rocprofiler-sdk-tool" in line for line in f)
+    except OSError:
+        return False
+
+
 @contextlib.contextmanager
 def _scoped_stream():
     """Current torch stream handle; synchronised when the scope ends (session.py:14-25)."""
@@ -294,6 +312,11 @@ class WhisperDecoderEngine:
             cur, _nu, done = self.poll()
         return self.read_ids(cur)
 
+    def stream(self, slots: int = 8, pool_rows: int = 0, max_length=None) -> "DecodeStream":
+        """Open a continuous decode on this engine (wt_decoder_stream_*): `slots` rows stay busy, every utterance stops at its own EOS
+        and its slot is refilled on the device within the same step.  Ends with the next `begin` / `generate` on this engine."""
+        return DecodeStream(self, slots, pool_rows, max_length)
+
     def set_profiling(self, enabled: bool):
         _lib.check(self.session._lib.wt_engine_set_profiling(self.session.handle, int(enabled)), "wt_engine_set_profiling")
 
@@ -322,6 +345,142 @@ class WhisperDecoderEngine:
         return t.ms_total, t.launches
 
 
+class DecodeStream:
+    """Continuous greedy decoding (the C-ABI's wt_decoder_stream_*): utterances are SUBMITTED as encoder memory, wait in a device-side
+    queue, and take over a decode slot the moment its previous utterance emits EOS (or reaches max_length) -- the per-utterance stop
+    the reference gets from transcribing one clip at a time (run.py:219-226), without a batch waiting for its longest row.
+
+        st = dec.stream(slots=8)
+        h = st.submit(enc(mel_chunk))             # handles, one per utterance; any number of chunks ahead (pool_rows bounds it)
+        st.run(min_waiting=8)                     # steps until fewer than 8 utterances wait (submit more) or everything has finished
+        for handle, ids in st.collect(): ...      # finished utterances (numpy int32 rows, start token .. EOS), cache rows released
+    """
+
+    def __init__(self, dec: "WhisperDecoderEngine", slots: int, pool_rows: int = 0, max_length=None):
+        import torch
+        self.dec, self.slots = dec, int(slots)
+        self._lib, self._h = dec.session._lib, dec.session.handle
+        self._p = dec._params(max_length, None, None)
+        self.max_length = int(self._p.max_length)
+        self.pool_rows = int(pool_rows) if pool_rows else 4 * self.slots
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self._lib.wt_decoder_stream_begin(self._h, self.slots, self.pool_rows, ctypes.byref(self._p), ctypes.c_void_p(stream)),
+                   "wt_decoder_stream_begin")
+        self._open: List[int] = []          # handles submitted and not collected yet, in submission order
+        self._keep: List[Any] = []          # encoder memories whose K/V projection may still be queued on the stream
+        self.n_submitted = 0
+        self.n_steps = 0
+
+    def free_rows(self) -> int:
+        return self.pool_rows - len(self._open)
+
+    def submit(self, encoder_hidden, force_eos_steps: Optional[Sequence[int]] = None) -> List[int]:
+        """Queue the utterances of `encoder_hidden` f32 [n, S, d] (n <= 16, n <= free_rows()); returns their handles."""
+        import torch
+        i = self.dec.session.info
+        if encoder_hidden.dtype != torch.float32 or tuple(encoder_hidden.shape[1:]) != (i.max_source_positions, i.d_model) or not encoder_hidden.is_cuda:
+            raise ValueError(f"encoder_hidden must be a CUDA float32 [n,{i.max_source_positions},{i.d_model}] tensor")
+        h = encoder_hidden.contiguous()
+        n = h.shape[0]
+        if force_eos_steps is not None and len(force_eos_steps) != n:
+            raise ValueError("force_eos_steps needs one entry per utterance")
+        fe = None
+        if force_eos_steps is not None:
+            fe, _ = _i32_array(force_eos_steps)
+        handles = (ctypes.c_int32 * n)()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self._lib.wt_decoder_stream_submit(self._h, h.data_ptr(), n, fe, handles, ctypes.c_void_p(stream)), "wt_decoder_stream_submit")
+        self._keep.append(h)
+        if len(self._keep) > 8:             # projections are stream-ordered: anything this old has long been consumed by later steps
+            self._keep.pop(0)
+        out = [int(x) for x in handles]
+        self._open.extend(out)
+        self.n_submitted += n
+        return out
+
+    def run(self, min_waiting: int = 0, lookahead: int = 0):
+        """Step until everything submitted has finished, or (min_waiting > 0) until fewer than `min_waiting` utterances still wait
+        for a slot.  Returns (finished so far, upper bound of utterances still waiting)."""
+        import torch
+        fin, wait, steps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self._lib.wt_decoder_stream_run(self._h, int(min_waiting), int(lookahead), ctypes.byref(fin), ctypes.byref(wait),
+                                                   ctypes.byref(steps), ctypes.c_void_p(stream)), "wt_decoder_stream_run")
+        self.n_steps = steps.value          # decoder steps enqueued since the stream was opened
+        return fin.value, wait.value
+
+    def collect(self):
+        """[(handle, ids)] of the utterances that have finished since the last call (numpy int32, start token through EOS / max_length);
+        their cache rows return to the pool."""
+        import numpy as np
+        out, still = [], []
+        buf = (ctypes.c_int32 * self.max_length)()
+        n = ctypes.c_int()
+        for h in self._open:
+            _lib.check(self._lib.wt_decoder_stream_collect(self._h, h, buf, self.max_length, ctypes.byref(n)), "wt_decoder_stream_collect")
+            if n.value > 0:
+                out.append((h, np.ctypeslib.as_array(buf)[:n.value].copy()))
+            else:
+                still.append(h)
+        self._open = still
+        return out
+
+
+def transcribe_continuous(enc: "WhisperEncoderEngine", dec: "WhisperDecoderEngine", mels, slots: int = 8, chunk: int = 8,
+                          force_eos_steps: Optional[Sequence[int]] = None, max_length=None, stats: Optional[dict] = None,
+                          pool_rows: int = 0) -> List[Any]:
+    """Encoder + continuous greedy decode of `mels` ([N, n_mels, 2*S] tensor or a list of such rows) in ARRIVAL order: the encoder runs
+    on chunks of `chunk` utterances just ahead of the decode, `slots` rows decode at any time.  Returns N numpy id rows (start token
+    through EOS) in input order.  This is the host scheduler of the C-ABI's continuous mode -- what cal_wer.py / run.py use for a
+    dataset whose transcripts differ in length.  `stats` (optional dict) receives the slot utilisation of the run."""
+    import torch
+    n = len(mels)
+    results: List[Any] = [None] * n
+    if n == 0:
+        return results
+    st = dec.stream(slots=slots, pool_rows=pool_rows, max_length=max_length)
+    index_of = {}
+    nxt = 0
+
+    def submit_next() -> int:
+        nonlocal nxt
+        k = min(chunk, n - nxt, st.free_rows())
+        if k <= 0:
+            return 0
+        part = mels[nxt:nxt + k]
+        x = part if torch.is_tensor(part) else torch.stack(list(part))
+        fe = None if force_eos_steps is None else [int(v) for v in force_eos_steps[nxt:nxt + k]]
+        for j, h in enumerate(st.submit(enc(x), fe)):
+            index_of[h] = nxt + j
+        nxt += k
+        return k
+
+    def harvest():
+        for h, ids in st.collect():
+            results[index_of.pop(h)] = ids
+
+    waiting = 0          # upper bound of the submitted utterances still waiting for a slot
+    while True:
+        # keep at least `slots` utterances waiting while there are more to come: a freed slot then never runs dry while the next
+        # chunk's encoder pass is still ahead
+        while nxt < n and waiting < slots and st.free_rows() > 0:
+            waiting += submit_next()
+        more = nxt < n
+        if more and st.free_rows() == 0:     # cache pool exhausted: step until one more utterance has been admitted (= one has finished)
+            _, waiting = st.run(min_waiting=max(1, waiting))
+        else:
+            _, waiting = st.run(min_waiting=slots if more else 0)
+        harvest()
+        if not more and not st._open:
+            break
+    assert all(r is not None for r in results)
+    if stats is not None:   # slot utilisation = row-steps that produced a token some utterance needed / row-steps paid for
+        stats["row_steps"] = int(sum(len(r) - 1 for r in results))
+        stats["steps"] = int(st.n_steps)
+        stats["slot_utilisation"] = stats["row_steps"] / float(max(1, st.n_steps) * slots)
+    return results
+
+
 class WhisperPipeline:
     """`workers` independent (encoder, decoder) engine pairs on ONE GPU, each driven by its own host thread on its own HIP stream.
 
@@ -331,13 +490,17 @@ class WhisperPipeline:
     on whisper-medium.en (434 vs 312 audio-s/s with 447-step decodes; DESIGN.md section 6 "Two workers per GPU").  Every worker is a
     complete execution context (own workspace, resident KV cache, step graphs: ~4 GB for medium.en fp32) on ONE shared, read-only copy
     of the weights (`wt_engine_clone`), so nothing mutable is shared and no lock is taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done).
-    (Not under `rocprofv3 --kernel-trace`: the profiler's interception of graph replays from several host threads at once crashes in
-    the runtime; profile one worker -- the kernels are the same.)"""
+    Under rocprofv3 (`under_rocprof()`) the pipeline clamps itself to ONE worker: concurrent graph replays from several host threads
+    aborted under the profiler in round 3 (cause not established, see `under_rocprof`); the kernels profiled are the same."""
 
     def __init__(self, encoder_buffer, decoder_buffer, config: dict, workers: int = 2, device: Optional[int] = None):
         import torch
         if workers < 1:
             raise ValueError("workers must be >= 1")
+        if workers > 1 and under_rocprof():
+            logger.warning(f"WhisperPipeline: rocprofv3 is loaded into this process -- running 1 worker instead of {workers} "
+                           "(concurrent graph replays from several host threads abort under the profiler; the kernels are the same)")
+            workers = 1
         self.device = torch.cuda.current_device() if device is None else device
         self.config = config
         enc0, dec0 = WhisperEncoderEngine(encoder_buffer, self.device), WhisperDecoderEngine(decoder_buffer, config, self.device)
@@ -365,6 +528,35 @@ class WhisperPipeline:
                 return dec.generate(enc(mel_batches[i]), **(gen_kwargs[i] if gen_kwargs is not None else {}))
 
         return run_workers(n, len(self.engines), item, setup=setup, teardown=lambda k: self.streams[k].synchronize())
+
+
+def _pipeline_transcribe_continuous(self, mels, slots: int = 8, chunk: int = 8, block: int = 64,
+                                    force_eos_steps: Optional[Sequence[int]] = None, max_length=None) -> List[Any]:
+    """Continuous decoding of `mels` ([N, n_mels, 2*S] CUDA tensor or list of rows) in ARRIVAL order: every worker takes blocks of `block`
+    utterances and runs them through its own continuous stream (`transcribe_continuous`: `slots` rows busy, per-utterance stop, slots
+    refilled on the device).  Returns N numpy id rows (start token through EOS) in input order."""
+    import torch
+    n = len(mels)
+    blocks = [(a, min(a + block, n)) for a in range(0, n, block)]
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(self.device))
+
+    def setup(k: int):
+        torch.cuda.set_device(self.device)
+        self.streams[k].wait_event(ready)
+
+    def item(k: int, j: int):
+        a, b = blocks[j]
+        enc, dec = self.engines[k]
+        with torch.cuda.stream(self.streams[k]):
+            return transcribe_continuous(enc, dec, mels[a:b], slots=slots, chunk=chunk, max_length=max_length,
+                                         force_eos_steps=None if force_eos_steps is None else force_eos_steps[a:b])
+
+    parts = run_workers(len(blocks), len(self.engines), item, setup=setup, teardown=lambda k: self.streams[k].synchronize())
+    return [row for part in parts for row in part]
+
+
+WhisperPipeline.transcribe_continuous = _pipeline_transcribe_continuous
 
 
 def run_workers(n_items: int, n_workers: int, item, setup=None, teardown=None) -> List[Any]:
