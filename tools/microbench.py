@@ -153,6 +153,32 @@ def bench_skinny_resident(B=8):
             print(f"skinny N={N} K={K} xmode={xmode} rotating {n_rot:2d} sets ({n_rot * N * K * 4 / 1e6:6.1f} MB): {us:7.2f} us")
 
 
+def bench_fold_fc1(B=8, L=24, d=1024, F=4096):
+    """fold the cross out-projection through LN3 into fc1 (6 launches per decoder layer instead of 7).
+    Today: cross_out (d x d, split-merged activations) + fc1 (LN + F x d + GELU) + fc2 (d x F).  Folded: ONE pair launch computing
+    h2 = h1 + Wco.ctx (d x d) and u = [G.Wco | G].[ctx ; h1] (F x 2d), then fc2 finishing x = gelu((u - mean.r).rstd + t) on its own
+    activation slice (every workgroup re-does the GELU of all B x F values it multiplies: 128 per lane).  Timing of both sides."""
+    X = torch.randn(B, d, device="cuda")
+    X2 = torch.randn(B, d, device="cuda")
+    g, be = torch.ones(d, device="cuda"), torch.zeros(d, device="cuda")
+    Wco = torch.randn(L, d, d, device="cuda") * 0.02
+    Wfc1 = torch.randn(L, F, d, device="cuda") * 0.02
+    Wfold = torch.randn(L, F, 2 * d, device="cuda") * 0.02
+    Wfc2 = torch.randn(L, d, F, device="cuda") * 0.02
+    bd, bF = torch.zeros(d, device="cuda"), torch.zeros(F, device="cuda")
+    Yd, YF = torch.empty(B, d, device="cuda"), torch.empty(B, F, device="cuda")
+    U = torch.randn(B, F, device="cuda")
+    r, t = torch.randn(F, device="cuda"), torch.randn(F, device="cuda")
+    us_co = timeit(lambda i: lib.wt_dbg_skinny(P(X), P(g), P(be), P(Wco[i]), P(bd), P(X2), P(Yd), B, d, d, 4, 0, 1.0, ST()), L)
+    us_fc1 = timeit(lambda i: lib.wt_dbg_skinny(P(X), P(g), P(be), P(Wfc1[i]), P(bF), None, P(YF), B, F, d, 5, 1, 1.0, ST()), L)
+    us_fc2 = timeit(lambda i: lib.wt_dbg_skinny(P(U), P(g), P(be), P(Wfc2[i]), P(bd), P(X2), P(Yd), B, d, F, 4, 0, 1.0, ST()), L)
+    us_pair = timeit(lambda i: lib.wt_dbg_skinny_pair(P(X), P(Wco[i]), P(bd), P(X2), P(Yd), d, d, P(X), P(X2), P(Wfold[i]), P(bF), P(YF), F, 2 * d, B, ST()), L)
+    us_fc2g = timeit(lambda i: lib.wt_dbg_skinny_gelu_in(P(U), P(r), P(t), P(Wfc2[i]), P(bd), P(X2), P(Yd), B, d, F, ST()), L)
+    print(f"today : cross_out {us_co:6.2f} + fc1 {us_fc1:6.2f} + fc2 {us_fc2:6.2f} = {us_co + us_fc1 + us_fc2:6.2f} us per layer")
+    print(f"folded: pair [d x d | F x 2d] {us_pair:6.2f} + fc2 with the GELU / LN finish in its prologue {us_fc2g:6.2f} = {us_pair + us_fc2g:6.2f} us per layer"
+          f"  (the prologue still lacks the LayerNorm statistics of the B rows: a lower bound)")
+
+
 def bench_gemm(M=12000):
     for (N, K, act) in ((3072, 1024, 0), (1024, 1024, 0), (4096, 1024, 1), (1024, 4096, 0), (2048, 1024, 0)):
         A = torch.randn(M, K, device="cuda")

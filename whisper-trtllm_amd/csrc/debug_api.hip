@@ -30,6 +30,7 @@ extern "C" int wt_dbg_layernorm(const float* x, const float* w, const float* b, 
 extern "C" int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, void* stream) {
     return rc_of(launch_encoder_attention(qkv, ctx, B, S, H, (hipStream_t)stream));
 }
+extern "C" int wt_dbg_encoder_attention_occupancy(void) { return encoder_attention_blocks_per_cu(); }
 extern "C" int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const float* W, const float* bias,
                              const float* resid, float* Y, int B, int N, int K, int xmode, int act, float scale,
                              void* stream) {
@@ -38,6 +39,14 @@ extern "C" int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_
     k.X = X; k.ln_w = ln_w; k.ln_b = ln_b; k.W = W; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B; k.N = N; k.K = K;
     k.xmode = xmode & 1; k.x_direct = (xmode >> 1) & 1; k.w_nt = (xmode >> 2) & 1; k.act = act; k.q_scale = scale; k.ymode = YMODE_PLAIN;
     return rc_of(launch_skinny(k, (hipStream_t)stream));
+}
+// probe (tools/microbench.py fold_fc1): fc2 with the GELU / LayerNorm finish of a folded fc1 in its prologue; timing only
+extern "C" int wt_dbg_skinny_gelu_in(const float* X, const float* r, const float* t, const float* W, const float* bias, const float* resid,
+                                     float* Y, int B, int N, int K, void* stream) {
+    SkinnyParams k;
+    memset(&k, 0, sizeof k);
+    k.X = X; k.ln_w = r; k.ln_b = t; k.W = W; k.bias = bias; k.resid = resid; k.Y = Y; k.B = B; k.N = N; k.K = K; k.w_nt = 1; k.q_scale = 1.f;
+    return rc_of(launch_skinny_gelu_in_probe(k, (hipStream_t)stream));
 }
 extern "C" int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt,
                                        float* out, int B, int H, int s_cap, int len, int n_split, void* stream) {

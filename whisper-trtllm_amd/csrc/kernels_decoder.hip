@@ -81,7 +81,9 @@ hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, co
 // column(v) = ks0 + 8*lane + 512*(v>>1) + 4*(v&1): the same 256*V columns per wave, the same activation registers and the same K-split
 // plan as the fp32 form, half the weight bytes per row (V/2 loads of 1 KiB per wave and row); the halves are widened with
 // v_cvt_f32_f16 right before the packed FMAs.
-template <int NB, int V, int NW, bool W_NT, bool HALF = false, bool ARGMAX = false, bool WH = false>
+// GELU_IN: PROBE ONLY (wt_dbg_skinny_gelu_in): the consumer side of "fold the cross out-projection through LN3 into
+// fc1" -- fc2 would have to finish x = gelu((u - mean.r).rstd + t) on its own activation slice.  Timing only (statistics are stand-ins).
+template <int NB, int V, int NW, bool W_NT, bool HALF = false, bool ARGMAX = false, bool WH = false, bool GELU_IN = false>
 __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsplit, const int KS, const int rows_per_group,
                                             const int block) {
     extern __shared__ __attribute__((aligned(16))) float sk_smem[];
@@ -314,6 +316,25 @@ __device__ __forceinline__ void skinny_body(const SkinnyParams& p, const int nsp
 #pragma unroll
             for (int v = 0; v < V; ++v)
                 if (!kok[v] || b >= p.B) xr[b][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (GELU_IN) {   // probe: what the folded-fc1 consumer would add in front of its products (128 GELUs per lane at K = 4096)
+            float4 rr[V], tt[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                rr[v] = *reinterpret_cast<const float4*>(p.ln_w + kcol[v]);
+                tt[v] = *reinterpret_cast<const float4*>(p.ln_b + kcol[v]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float mean = p.bias[min(b, p.N - 1)] * 1e-3f, rstd = 1.0f + mean;   // stand-ins for the LayerNorm statistics of row b
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    xr[b][v].x = gelu_erf((xr[b][v].x - mean * rr[v].x) * rstd + tt[v].x);
+                    xr[b][v].y = gelu_erf((xr[b][v].y - mean * rr[v].y) * rstd + tt[v].y);
+                    xr[b][v].z = gelu_erf((xr[b][v].z - mean * rr[v].z) * rstd + tt[v].z);
+                    xr[b][v].w = gelu_erf((xr[b][v].w - mean * rr[v].w) * rstd + tt[v].w);
+                }
+            }
+        }
     }
 
     // ARGMAX (a compile-time mode: its state would push the plain GEMVs of the step into register spills): running masked maximum
@@ -465,6 +486,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_gemm_kernel(c
     skinny_body<NB, V, NW, W_NT, false, ARGMAX, WH>(p, nsplit, KS, rows_per_group, blockIdx.x);
 }
 
+// probe (see GELU_IN above): the K > 1024 direct-activation GEMV with the GELU / LayerNorm finish in its prologue
+__global__ __launch_bounds__(256, 2) void skinny_gelu_in_probe_kernel(const SkinnyParams p, const int nsplit, const int KS, const int rows_per_group) {
+    skinny_body<8, 4, 4, true, false, false, false, true>(p, nsplit, KS, rows_per_group, blockIdx.x);
+}
+
 // Two GEMMs that depend on the same predecessor share ONE launch (the self-attention out-projection and the folded
 // cross-attention query): blocks [0, pa.grid) run `a`, the rest run `b`.  The branch is block-uniform.
 template <int NB, int V, int NW, bool HALF_B, bool WH = false>
@@ -579,6 +605,16 @@ static hipError_t skinny_pair_cfg(const SkinnyParams& a, const SkinnyParams& b, 
         if (b.parts && b.X2) hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, true>), grid, blk, smem, s, a, pa, b, pb);
         else hipLaunchKernelGGL((skinny_pair_kernel<NB, V, NW, false>), grid, blk, smem, s, a, pa, b, pb);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_skinny_gelu_in_probe(const SkinnyParams& p, hipStream_t s) {
+    if (p.B < 1 || p.B > 8 || p.K <= 1024 || p.xmode != XMODE_PLAIN || !p.ln_w || !p.ln_b || !p.bias) return hipErrorInvalidValue;
+    SkinnyPlan pl;
+    hipError_t e = skinny_plan<8, 4, 4>(p, &pl);
+    if (e != hipSuccess) return e;
+    constexpr int smem = (8 * 1024 + 2 * 4 * 2 * 8) * (int)sizeof(float);
+    hipLaunchKernelGGL(skinny_gelu_in_probe_kernel, dim3(pl.grid), dim3(256), smem, s, p, pl.nsplit, pl.KS, pl.rows_per_group);
     return hipGetLastError();
 }
 

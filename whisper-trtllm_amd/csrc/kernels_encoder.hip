@@ -641,6 +641,13 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
 constexpr int FA_BQ = 128, FA_BKV = 64, FA_LD = 68;
 constexpr int FA_SMEM = 2 * 2 * FA_BKV * FA_LD * (int)sizeof(float);  // 69,632 B
 
+// Round 4 tried four restructurings of this kernel against it on one box (profiles/r04_enc_attn_variants.txt: all within +-1 % of
+// 717 us per launch in the micro-benchmark): the V fragments of P.V requested a whole group of MFMAs ahead under pinned scheduling
+// (the compiler issues them one MFMA pair ahead with lgkmcnt(0) waits), the softmax's exponentials issued group by group in the shadow
+// of the previous group's MFMAs with the accumulator rescale skipped while no running maximum moves, the 256-VGPR budget two waves per
+// SIMD allow, and skipping the MFMAs of waves / half tiles that lie entirely in the 1500 -> 1536 padding.  None moved it: the LDS is
+// not the limit (SQ_WAIT_INST_LDS 1.4 % of the wave cycles, no bank conflicts: profiles/r04_enc_attn_pmc_counters.txt), and a wave's
+// spare MFMA time goes nowhere while its workgroup waits for its slowest wave at the per-tile barrier.  DESIGN.md section 9 has the reading.
 __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
                                                           int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -824,6 +831,14 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
                 make_float4(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
         }
     }
+}
+
+// workgroups of the attention kernel the runtime places on one CU (2: LDS admits two; checked on the box in round 4)
+int encoder_attention_blocks_per_cu() {
+    int n = -1;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_attn_kernel, 256, FA_SMEM) != hipSuccess) return -1;
+    return n;
 }
 
 hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s) {

@@ -172,6 +172,7 @@ hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s);
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
 hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s);
+int encoder_attention_blocks_per_cu();
 // fp16-encoder path (kernels_encoder_f16.hip): `void*` operands are __half buffers
 hipError_t launch_mel_transpose_h(const float* mel, void* melT, int B, int n_mels, int frames, hipStream_t s);
 hipError_t launch_layernorm_h(const float* x, const float* w, const float* b, void* y, int rows, int d, hipStream_t s);
@@ -182,6 +183,7 @@ hipError_t launch_encoder_attention_f16(const void* qkv, void* ctx, int B, int S
 hipError_t launch_dec_embed(const int* ids, int ids_ld, const float* tok_emb, const float* pos_emb, float* x, int B,
                             int d, const DecState* st, hipStream_t s, int emb_half = 0);   // emb_half: tok_emb is IEEE half
 hipError_t launch_skinny(const SkinnyParams& p, hipStream_t s);
+hipError_t launch_skinny_gelu_in_probe(const SkinnyParams& p, hipStream_t s);   // probe only (tools/microbench.py fold_fc1)
 int skinny_grid(const SkinnyParams& p);  // workgroups launch_skinny uses for p (column count of am_val / am_idx), -1 if p is invalid
 // two independent skinny GEMMs (same batch) in ONE launch: blocks [0, grid_a) run `a`, the rest run `b`
 hipError_t launch_skinny_pair(const SkinnyParams& a, const SkinnyParams& b, hipStream_t s);
