@@ -285,6 +285,15 @@ def main():
                 el2 = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
                 barrier()
                 varlen["length_sorted_workers"][str(nw)] = round(30.0 * n_utt * world / el2, 2)
+                # ... and the arrival-order workload through one continuous stream per worker (blocks of 32 utterances each)
+                pipe.transcribe_continuous(vmel[:2 * B], slots=B, chunk=B, block=32, force_eos_steps=eos_steps[:2 * B])
+                barrier()
+                t = time.perf_counter()
+                pipe.transcribe_continuous(vmel, slots=B, chunk=B, block=32, force_eos_steps=eos_steps)
+                torch.cuda.synchronize()
+                el2c = w.sharding.max_over_ranks(time.perf_counter() - t, dist)
+                barrier()
+                varlen.setdefault("continuous_workers", {})[str(nw)] = round(30.0 * n_utt * world / el2c, 2)
                 n2 = nw * max(1, min(args.steps, 3))   # bounded: the secondary legs must not scale with a large --steps
                 pipe.transcribe([mel] * nw)
                 barrier()

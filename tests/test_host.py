@@ -316,3 +316,94 @@ def test_under_rocprof_detection(monkeypatch):
     monkeypatch.delenv("LD_PRELOAD")
     monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
     assert w.runtime.under_rocprof()
+
+
+def test_continuous_scheduler_on_a_simulated_stream():
+    """runtime.transcribe_continuous (host scheduler of the continuous mode) against a SIMULATED DecodeStream (no GPU): every utterance
+    comes back exactly once in input order whatever the slot count, chunk size and cache-pool size; the pool is never over-committed;
+    the queue is topped up while utterances remain (no slot runs dry before the input is exhausted)."""
+    import numpy as np
+    import torch
+    import whisper_trtllm_amd as w
+
+    class FakeStream:
+        def __init__(self, slots, pool_rows, lengths):
+            self.slots, self.pool_rows, self.lengths = slots, pool_rows, lengths
+            self._open, self.n_steps, self.n_submitted = [], 0, 0
+            self.rows = {}            # handle -> [utterance id, remaining steps, state]  state: 0 waiting, 1 decoding, 2 finished
+            self.queue, self.active, self.dry_steps, self.exhausted = [], [], 0, False
+
+        def free_rows(self):
+            return self.pool_rows - len(self._open)
+
+        def submit(self, hidden, force_eos_steps=None):
+            n = hidden.shape[0]
+            assert 1 <= n <= 16 and n <= self.free_rows(), "pool over-committed"
+            used = set(self._open)
+            hs = [r for r in range(self.pool_rows) if r not in used][:n]
+            for j, h in enumerate(hs):
+                self.rows[h] = [int(hidden[j, 0, 0]), None, 0]
+                self.queue.append(h)
+            self._open.extend(hs)
+            self.n_submitted += n
+            return hs
+
+        def _admit(self):
+            while len(self.active) < self.slots and self.queue:
+                h = self.queue.pop(0)
+                self.rows[h][1], self.rows[h][2] = self.lengths[self.rows[h][0]], 1
+                self.active.append(h)
+
+        def run(self, min_waiting=0, lookahead=0):
+            self._admit()
+            while True:
+                if all(self.rows[h][2] == 2 for h in self._open):
+                    break
+                if min_waiting > 0 and len(self.queue) < min_waiting:
+                    break
+                self.n_steps += 1
+                if len(self.active) < self.slots and not self.exhausted:
+                    self.dry_steps += 1
+                for h in list(self.active):
+                    self.rows[h][1] -= 1
+                    if self.rows[h][1] == 0:
+                        self.rows[h][2] = 2
+                        self.active.remove(h)
+                self._admit()
+            return sum(1 for h in self._open if self.rows[h][2] == 2), len(self.queue)
+
+        def collect(self):
+            out = [(h, np.full(self.lengths[self.rows[h][0]] + 1, self.rows[h][0], dtype=np.int32)) for h in self._open if self.rows[h][2] == 2]
+            self._open = [h for h in self._open if self.rows[h][2] != 2]
+            return out
+
+    class FakeDec:
+        def __init__(self, lengths):
+            self.lengths, self.last = lengths, None
+
+        def stream(self, slots=8, pool_rows=0, max_length=None):
+            self.last = FakeStream(slots, pool_rows or 4 * slots, self.lengths)
+            return self.last
+
+    rng = np.random.default_rng(5)
+    for n, slots, chunk, pool in [(37, 8, 8, 0), (5, 8, 8, 0), (64, 3, 16, 0), (23, 2, 2, 3), (1, 1, 1, 2), (40, 4, 16, 5), (0, 4, 4, 0)]:
+        lengths = [int(x) for x in rng.integers(1, 40, size=max(n, 1))]
+        mels = torch.arange(n, dtype=torch.float32).reshape(n, 1, 1).repeat(1, 2, 3) if n else torch.zeros(0, 2, 3)
+        dec = FakeDec(lengths)
+        seen = []
+
+        def enc(x, dec=dec, seen=seen):     # the "encoder": utterance id in element [j, 0, 0]; the input is exhausted once the last id went by
+            seen.extend(int(v) for v in x[:, 0, 0])
+            if dec.last is not None and len(seen) == n:
+                dec.last.exhausted = True
+            return x
+
+        stats = {}
+        got = w.runtime.transcribe_continuous(enc, dec, mels, slots=slots, chunk=chunk, pool_rows=pool, stats=stats)
+        assert len(got) == n and seen == list(range(n))
+        for i in range(n):
+            assert len(got[i]) == lengths[i] + 1 and (got[i] == i).all()
+        if n:
+            assert stats["row_steps"] == sum(lengths[:n]) and stats["steps"] == dec.last.n_steps
+            if pool == 0 and chunk >= slots:     # a roomy pool and chunks of at least `slots`: a slot is idle only once the input is exhausted
+                assert dec.last.dry_steps == 0, (n, slots, chunk, dec.last.dry_steps)

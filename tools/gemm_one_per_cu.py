@@ -1,6 +1,6 @@
 """fp32 GEMM K loop with exactly 1, 2 or 3 workgroups per CU (256, 512, 768 tiles of 128x128, K = 4096): how close does ONE wave per SIMD
 get to the MFMA rate?  (Round 2: 117-119 TFLOP/s with 1 workgroup per CU, 130-132 with 2 or 3; a software-pipelined loop that kept
-one wave's MFMA queue full over the barrier reached 123 at 1 per CU and LOST 3 % at 2-3 per CU -- DESIGN.md section 6.)"""
+one wave's MFMA queue full over the barrier reached 123 at 1 per CU and LOST 3 % at 2-3 per CU -- DESIGN.md section 9.2.)"""
 import os
 import sys
 

@@ -487,7 +487,7 @@ class WhisperPipeline:
     Why: a greedy decode is a chain of ~170 dependent, launch-latency-bound kernels per token -- it leaves most of the chip idle
     most of the time -- while the encoder is MFMA-bound.  Batches are independent (the reference transcribes one clip after the
     other, run.py:262-290), so a second in-flight batch fills the first one's gaps: two workers of batch 8 measure ~1.4x one worker
-    on whisper-medium.en (434 vs 312 audio-s/s with 447-step decodes; DESIGN.md section 6 "Two workers per GPU").  Every worker is a
+    on whisper-medium.en (434 vs 312 audio-s/s with 447-step decodes; DESIGN.md section 6 "Workers per GPU").  Every worker is a
     complete execution context (own workspace, resident KV cache, step graphs: ~4 GB for medium.en fp32) on ONE shared, read-only copy
     of the weights (`wt_engine_clone`), so nothing mutable is shared and no lock is taken on the device path; `transcribe` hands the batches out dynamically (a worker takes the next batch when it is done).
     Under rocprofv3 (`under_rocprof()`) the pipeline clamps itself to ONE worker: concurrent graph replays from several host threads
