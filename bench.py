@@ -341,6 +341,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.encoder_precision == "float32" else "f16 encoder GEMM operands (f32 accumulate) + f32 decoder", "data": "synthetic",
         "config": {"workload": f"{args.model} {'fp32' if args.encoder_precision == 'float32' else 'fp16-encoder/fp32-decoder'} greedy, batch {B} per GPU x 30 s / 80x3000 synthetic log-mel, "
                                f"encoder + {args.max_length - 1} decoder steps (max_length {args.max_length}), random-init weights",
+                   "encoder_gemm": ("fp32 operands exactly split into three bf16 planes (x = b1 + b2 + b3 to 2^-27), six bf16 MFMAs per block, fp32 accumulate: "
+                                    "as accurate as the fp32 MFMA instruction (tests/test_gpu_kernels.py::test_gemm_x3_is_an_fp32_gemm)"
+                                    if enc.session._lib.wt_engine_gemm_mode(enc.session.handle) == 1 else "native MFMA of the engine's precision"),
                    "batch_per_gpu": B, "workers_per_gpu": args.workers, "decode_steps": args.max_length - 1, "sharding": f"utterance-parallel x{world}, no collective",
                    "value_n32_decode_steps": round(value_n32, 2),
                    "value_batch16_per_gpu": round(value_b16, 2) if value_b16 else None,
@@ -402,11 +405,23 @@ def main():
         attn_flop = B * cfg["encoder_layers"] * 4 * H * S * S * 64
         half = args.encoder_precision == "float16"
         enc_peak = 2500.0 if half else MFMA_F32_PEAK_TF
-        out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma4_kernel / gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
-                                   "achieved": round(gemm_tf, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(gemm_tf / enc_peak, 4),
-                                   "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
-                                   "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,
-                                   "enc_attn_total_ms": round(ms_eattn, 3)}
+        x3 = (not half) and enc_lib.wt_engine_gemm_mode(enc.session.handle) == 1
+        if x3:
+            # fp32 products formed on the bf16 matrix cores: every operand exactly split into three bf16 planes, six v_mfma_f32_32x32x16_bf16
+            # per block (DESIGN.md section 5 "fp32 GEMM on the bf16 matrix cores").  The roofline is the bf16 MFMA peak against the ISSUED bf16
+            # flops (6 x the useful fp32 ones); the useful rate is reported beside it, with the fp32 MFMA peak it replaces.
+            out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_x3_kernel (v_mfma_f32_32x32x16_bf16 x 6 per block: fp32 operands exactly split into three bf16 planes, fp32 accumulate)",
+                                       "achieved": round(6 * gemm_tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(6 * gemm_tf / 2500.0, 4),
+                                       "useful_fp32_tflops": round(gemm_tf, 2), "fp32_mfma_peak": MFMA_F32_PEAK_TF, "useful_vs_fp32_mfma_peak": round(gemm_tf / MFMA_F32_PEAK_TF, 4),
+                                       "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
+                                       "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,
+                                       "enc_attn_total_ms": round(ms_eattn, 3), "enc_attn_kernel": "enc_attn_kernel (v_mfma_f32_32x32x2_f32), peak 157.3"}
+        else:
+            out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma4_kernel / gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
+                                       "achieved": round(gemm_tf, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(gemm_tf / enc_peak, 4),
+                                       "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
+                                       "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,
+                                       "enc_attn_total_ms": round(ms_eattn, 3)}
         # whole decode phase against the HBM roofline: algorithmic bytes of step t for a batch of B =
         #   4*P_step + B*[ 4*L*2*H*S*64 (cross KV) + 4*L*2*H*(t+1)*64 (self KV read) + 4*L*2*H*64 (append) + 4*V (logits) ]
         n_steps = args.max_length - 1

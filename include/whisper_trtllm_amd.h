@@ -90,6 +90,11 @@ int wt_engine_clone(const wt_engine* src, wt_engine** out);
 /* (2) engine teardown (TensorRT: ICudaEngine/IExecutionContext destructors). */
 void wt_engine_close(wt_engine* e);
 int wt_engine_get_info(const wt_engine* e, wt_engine_info* out);
+/* How an fp32 engine forms its large matrix products: 0 = v_mfma_f32_32x32x2_f32 (the fp32 matrix instruction), 1 = "x3": every
+ * fp32 operand exactly split into three bf16 values (x = b1 + b2 + b3 to 2^-27 relative), the product accumulated in fp32 from the six
+ * partial products of order <= 2^-18 on v_mfma_f32_32x32x16_bf16 -- as accurate as the fp32 instruction (tests/test_gpu_kernels.py::
+ * test_gemm_x3_is_an_fp32_gemm) at 16 / 6 = 2.7x its peak.  The default for fp32 engines; fp16 engines report 0. */
+int wt_engine_gemm_mode(const wt_engine* e);
 
 /* (3) replaces Session.infer_shapes (session.py:116-146): check names/dtypes of the inputs, remember the
  * input shapes for the next run, and report the outputs.  `*n_out` is in: capacity of `out`, out: count.

@@ -36,6 +36,8 @@ int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const fl
 /* q [B][H*64] (pre-scaled), k/v cache [B][H][s_cap][64] with the first `len` rows valid -> out [B][H*64];
  * part: scratch [B][H][n_split][68]; cnt: int [B][H], must be zero on entry and is left zero */
 int wt_dbg_encoder_attention_occupancy(void);   /* workgroups of enc_attn_kernel per CU as the runtime computes it */
+int wt_dbg_gemm_x3(const float* A, const float* W, const float* bias, const float* resid, void* C, int M, int N, int K, int act,
+                   void* a_planes, void* w_planes, int flags, void* stream);   /* fp32 GEMM from bf16 MFMAs of exactly split operands; flags: 1 three-plane output, 2 planes already split */
 int wt_dbg_skinny_gelu_in(const float* X, const float* r, const float* t, const float* W, const float* bias, const float* resid, float* Y,
                           int B, int N, int K, void* stream);   /* probe: timing only */
 int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt, float* out,

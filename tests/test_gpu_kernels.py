@@ -51,6 +51,54 @@ def test_gemm(lib, M, N, K, act, use_res):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K,act,use_res,out_split", [
+    (128, 128, 16, 0, False, False), (128, 128, 32, 0, False, False), (200, 136, 240, 1, False, False), (1500, 384, 384, 0, True, False),
+    (97, 1000, 1536, 1, True, False), (1024, 3072, 1024, 0, False, False), (1500, 1536, 384, 1, False, True), (333, 200, 48, 1, False, True),
+    (4100, 3210, 64, 1, False, True), (12000, 1024, 4096, 0, True, False)])
+def test_gemm_x3_is_an_fp32_gemm(lib, M, N, K, act, use_res, out_split):
+    """launch_gemm_x3: the fp32 product formed on the bf16 matrix cores from exactly split operands (x = b1 + b2 + b3, six of the nine
+    partial products).  It must be AS ACCURATE AS the native fp32 MFMA kernel: both against fp64 on the same inputs, the split kernel's
+    error within 1.5x of the native kernel's (measured: equal or smaller), and inside the native test's absolute bar.  One to 256 K
+    steps (fewer than, as many as and more than its three pipeline stages), ragged tiles, every epilogue it is used with (plain, GELU,
+    residual in place, three-plane bf16 output)."""
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    # a few rows with a wide dynamic range and heavy cancellation: where dropping low-order bits would show first
+    A[:3] *= torch.tensor([1e3, 1e-3, 1.0]).view(3, 1)
+    A[3, 1::2] = -A[3, 0::2][: A[3, 1::2].numel()] * (1 + 1e-4)
+    R = _rand(M, N, seed=4) if use_res else None
+    ref = F.linear(A.double(), W.double(), b.double())
+    if act:
+        ref = F.gelu(ref)
+    if use_res:
+        ref = ref + R.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    a_pl = torch.empty(3 * M * K, dtype=torch.bfloat16, device="cuda")
+    w_pl = torch.empty(3 * N * K, dtype=torch.bfloat16, device="cuda")
+    if out_split:
+        C3 = torch.empty(3, M, N, dtype=torch.bfloat16, device="cuda")
+        assert lib.wt_dbg_gemm_x3(P(Ad), P(Wd), P(bd), None, P(C3), M, N, K, act, P(a_pl), P(w_pl), 1, _stream()) == 0
+        torch.cuda.synchronize()
+        got = C3.double().sum(0).cpu()          # b1 + b2 + b3, exact in fp64
+    else:
+        C = R.cuda().clone() if use_res else torch.empty(M, N, device="cuda")
+        assert lib.wt_dbg_gemm_x3(P(Ad), P(Wd), P(bd), P(C) if use_res else None, P(C), M, N, K, act, P(a_pl), P(w_pl), 0, _stream()) == 0
+        torch.cuda.synchronize()
+        got = C.cpu().double()
+    # the planes really are the exact split: plane sum == the fp32 operand to 2^-24 relative of each element
+    A3 = a_pl.view(3, M, K).double().sum(0).cpu()
+    assert ((A3 - A.double()).abs() <= A.double().abs() * 2.0 ** -24).all()
+    Cn = R.cuda().clone() if use_res else torch.empty(M, N, device="cuda")
+    assert lib.wt_dbg_gemm(P(Ad), K, P(Wd), P(bd), P(Cn) if use_res else None, P(Cn), M, N, K, act, _stream()) == 0
+    torch.cuda.synchronize()
+    err_x3 = (got - ref).abs().max().item()
+    err_native = (Cn.cpu().double() - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    print(f"gemm_x3 {M}x{N}x{K}: |err| {err_x3:.3e} (native fp32 MFMA {err_native:.3e}, |ref| {scale:.1f})")
+    slack = 2.0 ** -24 * scale if out_split else 0.0     # the three-plane output is itself rounded to 2^-27 .. 2^-24 of each element
+    assert err_x3 <= 1.5 * err_native + slack + 1e-7 * scale, (err_x3, err_native)
+    assert err_x3 < 2e-5 * scale
+
+
 @pytest.mark.parametrize("M,N,K,act,use_res", [
     # more than one round of 128x128 tiles (> 768 workgroups) with 3 (= pipeline depth), 4 and 16 K-steps per tile and ragged last
     # tile row / column: interior sub-tiles take the branch-free epilogue, edge sub-tiles the generic one, in the same launch;

@@ -189,6 +189,24 @@ def bench_gemm(M=12000):
         print(f"gemm M={M} N={N} K={K} act={act}: {us:8.1f} us  {2.0 * M * N * K / us * 1e-6:6.1f} TFLOP/s")
 
 
+def bench_gemm_x3(M=12000):
+    """launch_gemm_x3 (fp32 product from six bf16 MFMAs of exactly split operands) beside the native fp32 MFMA kernel on the encoder's
+    shapes; TFLOP/s of USEFUL fp32 work (2 M N K); the split kernel issues 6x that in bf16 MFMA flops."""
+    for (N, K, act) in ((3072, 1024, 0), (1024, 1024, 0), (4096, 1024, 1), (1024, 4096, 0), (2048, 1024, 0)):
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(4, N, K, device="cuda") * 0.03
+        bias = torch.zeros(N, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        a_pl = torch.empty(3 * M * K, dtype=torch.bfloat16, device="cuda")
+        w_pl = torch.empty(4, 3 * N * K, dtype=torch.bfloat16, device="cuda")
+        for i in range(4):
+            lib.wt_dbg_gemm_x3(P(A), P(W[i]), P(bias), None, P(C), M, N, K, act, P(a_pl), P(w_pl[i]), 0, ST())    # leaves the planes in place
+        us_n = timeit(lambda i: lib.wt_dbg_gemm(P(A), K, P(W[i]), P(bias), None, P(C), M, N, K, act, ST()), 4, iters=5)
+        us_h = timeit(lambda i: lib.wt_dbg_gemm_x3(P(A), P(W[i]), P(bias), None, P(C), M, N, K, act, P(a_pl), P(w_pl[i]), 2, ST()), 4, iters=5)
+        tf = lambda u: 2.0 * M * N * K / u * 1e-6
+        print(f"M={M} N={N} K={K} act={act}: native fp32 MFMA {us_n:8.1f} us {tf(us_n):6.1f} TF | x3 (planes in place) {us_h:8.1f} us {tf(us_h):6.1f} TF useful = {6 * tf(us_h):6.0f} TF of bf16 MFMA")
+
+
 def bench_gemm_shapes():
     """fp32 GEMM on the encoder shapes of medium.en / small.en (batch 8) and tiny.en (batch 1); run once per WT_GEMM_BN setting"""
     for (M, N, K) in ((12000, 1024, 1024), (12000, 1024, 4096), (12000, 2048, 1024), (12000, 3072, 1024), (12000, 4096, 1024),

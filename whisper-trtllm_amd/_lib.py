@@ -15,13 +15,13 @@ WT_NAME_LEN, WT_MAX_DIMS = 48, 6
 ABI_VERSION = 3
 
 EXPORTS = [
-    "wt_engine_open", "wt_engine_clone", "wt_engine_close", "wt_engine_get_info", "wt_engine_infer_shapes", "wt_engine_run",
+    "wt_engine_open", "wt_engine_clone", "wt_engine_close", "wt_engine_get_info", "wt_engine_gemm_mode", "wt_engine_infer_shapes", "wt_engine_run",
     "wt_encoder_forward", "wt_decoder_begin", "wt_decoder_steps", "wt_decoder_poll", "wt_decoder_run", "wt_decoder_read_ids",
     "wt_decoder_greedy", "wt_decoder_stream_begin", "wt_decoder_stream_submit", "wt_decoder_stream_run", "wt_decoder_stream_collect",
     "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
-DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_skinny_gelu_in", "wt_dbg_encoder_attention_occupancy", "wt_dbg_decode_attention",
+DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_x3", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_skinny_gelu_in", "wt_dbg_encoder_attention_occupancy", "wt_dbg_decode_attention",
                  "wt_dbg_decode_attention_folded", "wt_dbg_skinny_pair", "wt_dbg_attention_then_projection", "wt_dbg_self_attention_then_pair",
                  "wt_dbg_skinny_f16", "wt_dbg_decode_attention_f16", "wt_dbg_attention_then_projection_f16", "wt_dbg_skinny_pair_f16", "wt_dbg_gemm_f16_kv"]
 
@@ -83,6 +83,7 @@ def load():
     lib.wt_engine_close.argtypes = [c_void_p]
     lib.wt_engine_close.restype = None
     lib.wt_engine_get_info.argtypes = [c_void_p, POINTER(EngineInfo)]
+    lib.wt_engine_gemm_mode.argtypes = [c_void_p]
     lib.wt_engine_infer_shapes.argtypes = [c_void_p, POINTER(TensorDesc), c_int, POINTER(TensorDesc), POINTER(c_int)]
     lib.wt_engine_run.argtypes = [c_void_p, POINTER(Binding), c_int, POINTER(Binding), c_int, c_void_p]
     lib.wt_encoder_forward.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
@@ -106,6 +107,7 @@ def load():
     lib.wt_decoder_time_kernel.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_float), c_void_p]
     P, I, F = c_void_p, c_int, c_float
     lib.wt_dbg_gemm.argtypes = [P, I, P, P, P, P, I, I, I, I, P]
+    lib.wt_dbg_gemm_x3.argtypes = [P, P, P, P, P, I, I, I, I, P, P, I, P]
     lib.wt_dbg_gemm_stamps.argtypes = [P, I, P, P, P, P, I, I, I, I, P, P]
     lib.wt_dbg_gemm_f16.argtypes = [P, I, P, P, P, P, I, I, I, I, I, P]
     lib.wt_dbg_gemm_f16_variant.argtypes = [P, I, P, P, P, P, I, I, I, I, I, I, P]

@@ -24,6 +24,24 @@ extern "C" int wt_dbg_gemm_stamps(const float* A, int lda, const float* W, const
     g.c_rows_per_batch = M; g.M = M; g.N = N; g.K = K; g.act = act; g.dbg_stamps = stamps;
     return rc_of(launch_gemm_f32(g, (hipStream_t)stream));
 }
+// fp32 GEMM on the bf16 matrix cores (launch_gemm_x3): the hook splits A and W into the caller's scratch planes (3 * M * K and 3 * N * K
+// bf16) and multiplies; flags bit 0: C receives three bf16 planes of [M][N] instead of fp32; bit 1: skip the splitting (planes in place)
+extern "C" int wt_dbg_gemm_x3(const float* A, const float* W, const float* bias, const float* resid, void* C, int M, int N, int K, int act,
+                              void* a_planes, void* w_planes, int flags, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int out_split = flags & 1;
+    int rc = 0;
+    if (!(flags & 2)) {   // bit 1: the planes are in place already (timing of the product alone)
+        if ((rc = rc_of(launch_split3(A, a_planes, (size_t)M * K, (size_t)M * K, s)))) return rc;
+        if ((rc = rc_of(launch_split3(W, w_planes, (size_t)N * K, (size_t)N * K, s)))) return rc;
+    }
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = (const float*)a_planes; g.lda = K; g.a_rows_per_batch = M; g.a_plane = (long long)M * K; g.W = (const float*)w_planes; g.w_plane = (long long)N * K;
+    g.bias = bias; g.resid = resid; g.C = (float*)C; g.ldc = N; g.c_rows_per_batch = M; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.out_split = out_split; g.c_plane = (long long)M * N;
+    return rc_of(launch_gemm_x3(g, s));
+}
 extern "C" int wt_dbg_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, void* stream) {
     return rc_of(launch_layernorm(x, w, b, y, rows, d, (hipStream_t)stream));
 }

@@ -49,12 +49,14 @@ struct DevTensor {
 
 struct EncLayerW {
     const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    const void *qkv_w3 = nullptr, *o_w3 = nullptr, *fc1_w3 = nullptr, *fc2_w3 = nullptr;   // the same matrices as three bf16 planes (launch_gemm_x3)
 };
 struct DecLayerW {
     const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b;
     const float *fold_w, *fold_c, *fold_r, *fold_t;  // folded LN + cross-attention query (builder.py:_pack_decoder)
     const float *ckv_w, *ckv_b, *co_w, *co_b;
     const float *ln3_w, *ln3_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    const void* ckv_w3 = nullptr;   // cross k|v weights as three bf16 planes (launch_gemm_x3)
 };
 
 struct EvTimer {
@@ -68,11 +70,13 @@ struct EvTimer {
 // handles wt_engine_clone makes from it -- N workers per GPU (runtime.WhisperPipeline) hold one copy of the weights and N workspaces.
 struct WeightStore {
     char* base = nullptr;
+    char* x3 = nullptr;    // fp32 engines: the big GEMMs' weights once more as three bf16 planes each (launch_gemm_x3), shared like `base`
     int device = 0;
     ~WeightStore() {
-        if (!base) return;
+        if (!base && !x3) return;
         DeviceGuard guard(device);
-        hipFree(base);
+        if (base) hipFree(base);
+        if (x3) hipFree(x3);
     }
 };
 
@@ -89,6 +93,9 @@ struct wt_engine {
     int enc_cap = 0;
     char* enc_ws = nullptr;
     float *melT = nullptr, *c1 = nullptr, *hbuf = nullptr, *xbuf = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
+    bool use_x3 = false;          // fp32 engine: the layer GEMMs / the cross-K/V projection run launch_gemm_x3 (fp32 product from bf16 MFMAs)
+    void *xs3 = nullptr, *ctx3 = nullptr, *ffn3 = nullptr;   // x3 activations: three bf16 planes of [M][d] / [M][d] / [M][F]
+    void* enc3 = nullptr;         // decoder: three bf16 planes of the encoder memory in front of the cross-K/V projection
     void *melT_h = nullptr, *c1_h = nullptr, *x_h = nullptr, *ctx_h = nullptr, *ffn_h = nullptr;  // fp16 engines
     // decoder
     std::vector<DecLayerW> dec_layers;
@@ -210,6 +217,40 @@ extern "C" void wt_engine_close(wt_engine* e) {
     if (e->dec_ws) hipFree(e->dec_ws);
     e->weights.reset();   // the last handle sharing the payload frees it
     delete e;
+}
+
+// Split the weight matrices of the big GEMMs into three bf16 planes each (one extra allocation, shared by clones like the payload).
+static int build_x3_weights(wt_engine* e) {
+    const size_t d = e->d, F = e->F;
+    struct Job { const float* src; size_t n; const void** dst; };
+    std::vector<Job> jobs;
+    if (e->kind == WT_KIND_ENCODER)
+        for (EncLayerW& l : e->enc_layers) {
+            jobs.push_back({l.qkv_w, 3 * d * d, &l.qkv_w3}); jobs.push_back({l.o_w, d * d, &l.o_w3});
+            jobs.push_back({l.fc1_w, F * d, &l.fc1_w3}); jobs.push_back({l.fc2_w, d * F, &l.fc2_w3});
+        }
+    else
+        for (DecLayerW& l : e->dec_layers) jobs.push_back({l.ckv_w, 2 * d * d, &l.ckv_w3});
+    size_t total = 0;
+    for (const Job& j : jobs) total += align_up(j.n * 6, 256);
+    if (!total) return WT_OK;
+    hipError_t he = hipMalloc((void**)&e->weights->x3, total);
+    if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for the split weights failed: %s", total, hipGetErrorString(he));
+    hipStream_t up = nullptr;
+    he = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+    size_t off = 0;
+    for (const Job& j : jobs) {
+        if (he != hipSuccess) break;
+        void* dst = e->weights->x3 + off;
+        he = launch_split3(j.src, dst, j.n, j.n, up);
+        *j.dst = dst;
+        off += align_up(j.n * 6, 256);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(up);
+    if (up) hipStreamDestroy(up);
+    if (he != hipSuccess) return fail(WT_E_HIP, "splitting the weights failed: %s", hipGetErrorString(he));
+    e->use_x3 = true;
+    return WT_OK;
 }
 
 extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_engine** out) {
@@ -337,6 +378,16 @@ extern "C" int wt_engine_open(const void* blob, size_t nbytes, int device, wt_en
         snprintf(g_err, sizeof g_err, "%s", keep.c_str());
         return WT_E_INVALID;
     }
+    {   // fp32 engines: the weights of the big GEMMs once more as three bf16 planes (wt_common.h: launch_gemm_x3)
+        static const bool x3_on = !(tuning_env("WT_GEMM_X3") && atoi(tuning_env("WT_GEMM_X3")) == 0);   // A/B switch: native fp32 MFMA GEMMs
+        const int rc = (x3_on && e->precision == WT_F32 && (e->d % 16) == 0 && (e->F % 16) == 0) ? build_x3_weights(e) : WT_OK;
+        if (rc) {
+            std::string keep = g_err;
+            wt_engine_close(e);
+            snprintf(g_err, sizeof g_err, "%s", keep.c_str());
+            return rc;
+        }
+    }
     *out = e;
     return WT_OK;
 }
@@ -355,7 +406,7 @@ extern "C" int wt_engine_clone(const wt_engine* src, wt_engine** out) {
     e->enc_pos = src->enc_pos; e->enc_ln_w = src->enc_ln_w; e->enc_ln_b = src->enc_ln_b;
     e->dec_layers = src->dec_layers;
     e->tok_emb = src->tok_emb; e->pos_emb = src->pos_emb; e->proj_w = src->proj_w; e->dec_ln_w = src->dec_ln_w; e->dec_ln_b = src->dec_ln_b;
-    e->w_half = src->w_half; e->kv_esz = src->kv_esz;
+    e->w_half = src->w_half; e->kv_esz = src->kv_esz; e->use_x3 = src->use_x3;
     // workspace, resident caches, step graphs, streams, mailbox, timers: this handle's own, allocated on first use like a fresh engine's
     *out = e;
     return WT_OK;
@@ -369,6 +420,8 @@ extern "C" int wt_engine_get_info(const wt_engine* e, wt_engine_info* out) {
     return WT_OK;
 }
 
+extern "C" int wt_engine_gemm_mode(const wt_engine* e) { return e && e->use_x3 ? 1 : 0; }
+
 // ------------------------------------------------------------------------------------------------- encoder
 // (workspace clears are stream-ordered on the CALLER's stream: a synchronous hipMemset runs on the legacy stream, which the runtime
 // refuses while ANOTHER host thread -- another worker's handle -- is capturing its step graph)
@@ -381,12 +434,15 @@ static int enc_reserve(wt_engine* e, int B, hipStream_t s) {
     const size_t o_melT = take((size_t)B * (Fr + 2) * e->C + 4 * e->C);
     const size_t o_c1 = take((size_t)B * (Fr + 2) * d + 4 * d);
     const size_t o_h = take(M * d), o_x = take(M * d), o_qkv = take(M * 3 * d), o_ctx = take(M * d), o_ffn = take(M * e->F);
+    // x3 GEMMs: their A operands as three bf16 planes (6 bytes per element = 1.5 floats)
+    const size_t o_xs3 = take(e->use_x3 ? (M * d * 3 + 1) / 2 : 0), o_ctx3 = take(e->use_x3 ? (M * d * 3 + 1) / 2 : 0), o_ffn3 = take(e->use_x3 ? (M * e->F * 3 + 1) / 2 : 0);
     // fp16 engines reuse the fp32-sized regions for their half-precision activations (half the bytes)
     hipError_t he = hipMalloc((void**)&e->enc_ws, off);
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for encoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     e->melT = (float*)(e->enc_ws + o_melT); e->c1 = (float*)(e->enc_ws + o_c1); e->hbuf = (float*)(e->enc_ws + o_h);
     e->xbuf = (float*)(e->enc_ws + o_x); e->qkv = (float*)(e->enc_ws + o_qkv); e->ctx = (float*)(e->enc_ws + o_ctx);
     e->ffn = (float*)(e->enc_ws + o_ffn);
+    e->xs3 = e->enc_ws + o_xs3; e->ctx3 = e->enc_ws + o_ctx3; e->ffn3 = e->enc_ws + o_ffn3;
     e->melT_h = e->melT; e->c1_h = e->c1; e->x_h = e->xbuf; e->ffn_h = e->ffn;
     e->ctx_h = (char*)e->ffn + M * e->F * 2;  // second half of the ffn region (M*F*2 bytes >= M*d*2)
     // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
@@ -496,6 +552,41 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
         q.C = Cout; q.ldc = N; q.c_rows_per_batch = M; q.resid = resid;
         return timed_gemm(e, q, s);
     };
+    // launch_gemm_x3 form of a layer GEMM: A / W as three bf16 planes, fp32 (or, for fc1, three-plane) output
+    auto dense3 = [&](const void* A3, int K, const void* W3, const float* bias, int N, void* Cout, int act, const float* resid, bool out_split) {
+        GemmParams q;
+        memset(&q, 0, sizeof q);
+        q.A = (const float*)A3; q.lda = K; q.a_rows_per_batch = M; q.a_plane = (long long)M * K; q.W = (const float*)W3; q.w_plane = (long long)N * K;
+        q.bias = bias; q.M = M; q.N = N; q.K = K; q.act = act; q.C = (float*)Cout; q.ldc = N; q.c_rows_per_batch = M; q.resid = resid;
+        q.out_split = out_split ? 1 : 0; q.c_plane = (long long)M * N;
+        hipEvent_t a, b;
+        timer_begin(e, e->t_gemm, s, &a, &b);
+        LAUNCH(launch_gemm_x3(q, s));
+        timer_end(e, e->t_gemm, s, a, b);
+        return WT_OK;
+    };
+    if (e->use_x3) {
+        // fp32 products formed from six bf16 MFMAs of exactly split operands (wt_common.h: launch_gemm_x3): every producer of a GEMM's
+        // A operand -- LayerNorm, attention, fc1's GELU epilogue -- writes the three planes directly, so no extra pass splits anything
+        const size_t pl_d = (size_t)M * d;
+        for (int i = 0; i < e->L; ++i) {
+            const EncLayerW& l = e->enc_layers[i];
+            LAUNCH(launch_layernorm_split(e->hbuf, l.ln1_w, l.ln1_b, e->xs3, pl_d, M, d, s));
+            if ((rc = dense3(e->xs3, d, l.qkv_w3, l.qkv_b, 3 * d, e->qkv, 0, nullptr, false))) return rc;
+            {
+                hipEvent_t a, b;
+                timer_begin(e, e->t_enc_attn, s, &a, &b);
+                LAUNCH(launch_encoder_attention(e->qkv, nullptr, B, S, e->H, s, e->ctx3, pl_d));
+                timer_end(e, e->t_enc_attn, s, a, b);
+            }
+            if ((rc = dense3(e->ctx3, d, l.o_w3, l.o_b, d, e->hbuf, 0, e->hbuf, false))) return rc;
+            LAUNCH(launch_layernorm_split(e->hbuf, l.ln2_w, l.ln2_b, e->xs3, pl_d, M, d, s));
+            if ((rc = dense3(e->xs3, d, l.fc1_w3, l.fc1_b, e->F, e->ffn3, 1, nullptr, true))) return rc;
+            if ((rc = dense3(e->ffn3, e->F, l.fc2_w3, l.fc2_b, d, e->hbuf, 0, e->hbuf, false))) return rc;
+        }
+        LAUNCH(launch_layernorm(e->hbuf, e->enc_ln_w, e->enc_ln_b, out, M, d, s));
+        return WT_OK;
+    }
     for (int i = 0; i < e->L; ++i) {
         const EncLayerW& l = e->enc_layers[i];
         LAUNCH(launch_layernorm(e->hbuf, l.ln1_w, l.ln1_b, e->xbuf, M, d, s));
@@ -531,6 +622,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s, int p
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_sk = take(kv_self * e->kv_esz), o_sv = take(kv_self * e->kv_esz), o_ck = take(kv_cross * e->kv_esz), o_cv = take(kv_cross * e->kv_esz);
     const size_t o_ench = take(e->w_half ? (size_t)enc_rows * e->S * d * 2 : 0);
+    const size_t o_enc3 = take(e->use_x3 ? (size_t)enc_rows * e->S * d * 6 : 0);
     const size_t o_h = take((size_t)B * d * 4), o_h2 = take((size_t)B * d * 4), o_q = take((size_t)B * d * 4), o_att = take((size_t)B * d * 4), o_f = take((size_t)B * e->F * 4);
     const size_t o_cnt = take((size_t)B * e->H * 4);
     const size_t o_selv = take((size_t)B * SEL_PARTS_CAP * 4), o_seli = take((size_t)B * SEL_PARTS_CAP * 4);
@@ -546,6 +638,7 @@ static int dec_reserve(wt_engine* e, int B, int max_length, hipStream_t s, int p
     e->forced = (int*)(b + o_forced); e->mask = (uint8_t*)(b + o_mask); e->force_rows = (int*)(b + o_frows);
     e->h_force_rows.clear();
     e->enc_h = e->w_half ? (void*)(b + o_ench) : nullptr;
+    e->enc3 = e->use_x3 ? (void*)(b + o_enc3) : nullptr;
     HIPCHK(hipMemsetAsync(e->att_cnt, 0, (size_t)B * e->H * 4, s));  // arrival tickets start (and are left) at zero; stream-ordered (see enc_reserve)
     if (!e->h_state) HIPCHK(hipHostMalloc((void**)&e->h_state, sizeof(DecState), hipHostMallocDefault));
     if (!e->mailbox) {
@@ -717,6 +810,16 @@ static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int ro
     if (row0 < 0 || row0 + B > layer_rows) return fail(WT_E_INVALID, "cross_kv_project: rows [%d, %d) outside a cache of %d rows per layer", row0, row0 + B, layer_rows);
     const size_t row_bytes = (size_t)e->H * e->S * HEAD_DIM * kv_esz;
     if (e->w_half) LAUNCH(launch_cast_h(enc_hidden, e->enc_h, (size_t)B * e->S * d, s));
+    const size_t enc_plane = (size_t)B * e->S * d;
+    bool x3 = e->use_x3 && !e->w_half && B <= (e->dec_cap > MAX_ROWS ? e->dec_cap : MAX_ROWS);
+    if (x3) {   // the encoder memory as three bf16 planes (the x3 GEMM's A operand)
+        GemmParams t;
+        memset(&t, 0, sizeof t);
+        t.A = (const float*)e->enc3; t.lda = d; t.a_rows_per_batch = rows; t.a_batch_stride = (long long)e->S * d; t.a_plane = (long long)enc_plane;
+        t.W = (const float*)e->dec_layers[0].ckv_w3; t.w_plane = 2ll * d * d; t.M = B * rows; t.N = 2 * d; t.K = d; t.c_rows_per_batch = rows;
+        x3 = gemm_x3_usable(t);
+        if (x3) LAUNCH(launch_split3(enc_hidden, e->enc3, enc_plane, enc_plane, s));
+    }
     for (int i = 0; i < e->L; ++i) {
         const DecLayerW& l = e->dec_layers[i];
         const size_t layer = ((size_t)i * layer_rows + row0) * row_bytes;
@@ -730,6 +833,12 @@ static int cross_kv_project(wt_engine* e, const float* enc_hidden, int B, int ro
             hipEvent_t ta, tb;
             timer_begin(e, e->t_gemm, s, &ta, &tb);
             LAUNCH(launch_gemm_f16(g, kv_esz == 2, s));
+            timer_end(e, e->t_gemm, s, ta, tb);
+        } else if (x3) {
+            g.A = (const float*)e->enc3; g.a_plane = (long long)enc_plane; g.W = (const float*)l.ckv_w3; g.w_plane = 2ll * d * d;
+            hipEvent_t ta, tb;
+            timer_begin(e, e->t_gemm, s, &ta, &tb);
+            LAUNCH(launch_gemm_x3(g, s));
             timer_end(e, e->t_gemm, s, ta, tb);
         } else {
             int rc = timed_gemm(e, g, s);

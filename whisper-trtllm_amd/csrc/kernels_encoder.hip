@@ -15,6 +15,25 @@ namespace wt {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// fp32 -> three bf16 planes: b1 = rn(x), b2 = rn(x - b1), b3 = rn(x - b1 - b2); x = b1 + b2 + b3 to 2^-27 relative (wt_common.h: launch_gemm_x3)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(const float x, __bf16& b1, __bf16& b2, __bf16& b3) {
+    b1 = (__bf16)x;
+    const float r1 = x - (float)b1;
+    b2 = (__bf16)r1;
+    b3 = (__bf16)(r1 - (float)b2);
+}
+__device__ __forceinline__ void store_split3(float* base, const long long off, const long long plane, const float x) {
+    __bf16 b1, b2, b3;
+    split3(x, b1, b2, b3);
+    __bf16* o = reinterpret_cast<__bf16*>(base) + off;
+    o[0] = b1;
+    o[plane] = b2;
+    o[2 * plane] = b3;
+}
+
+
 
 // ------------------------------------------------------------------------------------------------ mel transpose
 // mel [B][C][F] (time contiguous, the layout of run.py's `input_features`) -> melT [B][F+2][C], row = time+1,
@@ -56,9 +75,11 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
     return v;
 }
 
+// SPLIT: the normalised row goes out as three bf16 planes (the A operand of launch_gemm_x3; `y` = plane 0, plane p at + p * plane elements)
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int rows,
-                                                        int d) {
+                                                        int d, size_t plane) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
@@ -94,21 +115,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.y = (v[i].y - mean) * rstd * g.y + be.y;
             o.z = (v[i].z - mean) * rstd * g.z + be.z;
             o.w = (v[i].w - mean) * rstd * g.w + be.w;
-            yr[c] = o;
+            if (SPLIT) {
+                __bf16* o0 = reinterpret_cast<__bf16*>(y) + (size_t)row * d + 4 * c;
+                bf16x4 p1, p2, p3;
+                __bf16 b1, b2, b3;
+                split3(o.x, b1, b2, b3); p1[0] = b1; p2[0] = b2; p3[0] = b3;
+                split3(o.y, b1, b2, b3); p1[1] = b1; p2[1] = b2; p3[1] = b3;
+                split3(o.z, b1, b2, b3); p1[2] = b1; p2[2] = b2; p3[2] = b3;
+                split3(o.w, b1, b2, b3); p1[3] = b1; p2[3] = b2; p3[3] = b3;
+                *reinterpret_cast<bf16x4*>(o0) = p1;
+                *reinterpret_cast<bf16x4*>(o0 + plane) = p2;
+                *reinterpret_cast<bf16x4*>(o0 + 2 * plane) = p3;
+            } else {
+                yr[c] = o;
+            }
         }
     }
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s) {
     if (d > 1280 || (d & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, d);
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, d, (size_t)0);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm_split(const float* x, const float* w, const float* b, void* planes, size_t plane_stride, int rows, int d, hipStream_t s) {
+    if (d > 1280 || (d & 3) || (plane_stride & 3) || ((uintptr_t)planes & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, reinterpret_cast<float*>(planes), rows, d, plane_stride);
     return hipGetLastError();
 }
 
-// Epilogue shared by the two fp32 GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// Epilogue shared by the fp32 GEMM kernels (and gemm_x3_kernel, whose 32x32x16 bf16 MFMAs leave the same accumulator layout).  C/D layout
+// of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-template <int TJ>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][TJ], const int m0, const int n0, const int wr,
+template <int TJ, int TI = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[TI][TJ], const int m0, const int n0, const int wr,
                                               const int wc, const int l31, const int hh) {
     // Row-dependent addressing (batch split, output row pointer) is computed once per row -- the batch index of the
     // wave's first row by ONE wave-uniform division, the rest by carry -- and the residual / position rows of a group of
@@ -134,7 +174,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     const int mw = m0 + wr * 64;                       // first row of this wave (wave-uniform)
     const int cb_w = mw / p.c_rows_per_batch, cr_w = mw - cb_w * p.c_rows_per_batch;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             long long offs[4];
@@ -171,7 +211,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
                     if (p.act) v = gelu_erf(v);
                     v += posv[ri][tj];
                     if (p.epi == EPI_ROWMAJOR) {
-                        p.C[offs[ri] + nn[tj]] = v + extra[ri][tj];
+                        if (p.out_split) store_split3(p.C, offs[ri] + nn[tj], p.c_plane, v + extra[ri][tj]);
+                        else p.C[offs[ri] + nn[tj]] = v + extra[ri][tj];
                     } else {
                         float* base = kv_which[tj] ? p.C2 : p.C;
                         base[offs[ri] + (long long)kv_h[tj] * p.kv_cap * HEAD_DIM + kv_j[tj]] = v;
@@ -186,8 +227,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
 // loads -- never for the stores.  (gfx9 has ONE counter for loads and stores: in the generic epilogue above every `p.resid ? load : 0`
 // becomes a branch whose join waits vmcnt(0), i.e. for the round trip of all stores issued so far; measured per workgroup, its stores
 // took 13 us to ISSUE alone on a CU and 60 us beside other workgroups' K loops -- a third of a K = 1024 tile's life.)
-template <bool RESID, bool ACT, bool POS, bool KV, int TJ>
-__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[2][TJ], const int m0, const int n0, const int wr,
+template <bool RESID, bool ACT, bool POS, bool KV, int TJ, bool SPLIT = false, int TI = 2>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x16 (&acc)[TI][TJ], const int m0, const int n0, const int wr,
                                                    const int wc, const int l31, const int hh) {
     const int mw = m0 + wr * 64, rpb = p.c_rows_per_batch;
     const int cb_w = mw / rpb, cr_w = mw - cb_w * rpb;                 // wave-uniform: one division
@@ -233,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
     };
     if (RESID || POS) { fetch(0); fetch(1); }
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 4 * TI; ++g) {
         float v[8];
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri)
@@ -250,27 +291,34 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f3
             int cr;
             const int off = row_of(g, ri, cr);
 #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj) base[tj][off + col[tj]] = v[ri * 2 + tj];
+            for (int tj = 0; tj < TJ; ++tj) {
+                if (SPLIT) store_split3(base[tj], off + col[tj], p.c_plane, v[ri * 2 + tj]);
+                else base[tj][off + col[tj]] = v[ri * 2 + tj];
+            }
         }
-        if ((RESID || POS) && g + 2 < 8) fetch(g + 2);
+        if ((RESID || POS) && g + 2 < 4 * TI) fetch(g + 2);
     }
 }
 
 // Epilogue dispatch: the fast form for interior sub-tiles of the operand combinations the engines use, the generic one otherwise.
-template <int TJ>
-__device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[2][TJ], const int m0, const int n0, const int wr,
+template <int TJ, int TI = 2>
+__device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32x16 (&acc)[TI][TJ], const int m0, const int n0, const int wr,
                                                   const int wc, const int l31, const int hh) {
-    const bool interior = m0 + wr * 64 + 64 <= p.M && n0 + wc * (32 * TJ) + 32 * TJ <= p.N && p.c_rows_per_batch >= 64 && p.epi_fits32;
-    if (interior && p.epi == EPI_ROWMAJOR && !p.pos) {
-        if (p.resid && !p.act) return gemm_epilogue_fast<true, false, false, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
-        if (!p.resid && p.act) return gemm_epilogue_fast<false, true, false, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
-        if (!p.resid && !p.act) return gemm_epilogue_fast<false, false, false, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
-    } else if (interior && p.epi == EPI_ROWMAJOR && p.pos && p.act && !p.resid) {
-        return gemm_epilogue_fast<false, true, true, false, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
-    } else if (interior && p.epi == EPI_KV_HEADS && !p.pos && !p.act && !p.resid) {
-        return gemm_epilogue_fast<false, false, false, true, TJ>(p, acc, m0, n0, wr, wc, l31, hh);
+    const bool interior = m0 + wr * 64 + 32 * TI <= p.M && n0 + wc * (32 * TJ) + 32 * TJ <= p.N && p.c_rows_per_batch >= 64 && p.epi_fits32;
+    if (p.out_split) {   // three bf16 planes out (the A operand of the next launch_gemm_x3): fc1's GELU output
+        if (interior && p.epi == EPI_ROWMAJOR && !p.pos && !p.resid && p.act) return gemm_epilogue_fast<false, true, false, false, TJ, true, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+        return gemm_epilogue<TJ, TI>(p, acc, m0, n0, wr, wc, l31, hh);
     }
-    gemm_epilogue<TJ>(p, acc, m0, n0, wr, wc, l31, hh);
+    if (interior && p.epi == EPI_ROWMAJOR && !p.pos) {
+        if (p.resid && !p.act) return gemm_epilogue_fast<true, false, false, false, TJ, false, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (!p.resid && p.act) return gemm_epilogue_fast<false, true, false, false, TJ, false, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (!p.resid && !p.act) return gemm_epilogue_fast<false, false, false, false, TJ, false, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+    } else if (interior && p.epi == EPI_ROWMAJOR && p.pos && p.act && !p.resid) {
+        return gemm_epilogue_fast<false, true, true, false, TJ, false, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+    } else if (interior && p.epi == EPI_KV_HEADS && !p.pos && !p.act && !p.resid) {
+        return gemm_epilogue_fast<false, false, false, true, TJ, false, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+    }
+    gemm_epilogue<TJ, TI>(p, acc, m0, n0, wr, wc, l31, hh);
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
@@ -630,6 +678,225 @@ hipError_t launch_gemm_f32(const GemmParams& p_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 GEMM on the bf16 matrix cores
+// C = epi(A . W^T) with A and W given as THREE bf16 planes each (wt_common.h: launch_gemm_x3): per 32x32x16 block six
+// v_mfma_f32_32x32x16_bf16 -- a3.w1, a1.w3, a2.w2, a2.w1, a1.w2, a1.w1, small terms first -- into ONE fp32 accumulator, which is the
+// accumulator (and the accumulator layout) of the fp32 kernel, so the epilogues above are shared.  Structure of gemm_f32_dma_kernel:
+// 128x128 tile, 4 waves (2x2) x 2x2 blocks, K step 16; every plane tile is 128 rows x 32 B, staged by LDS-DMA (one 1 KiB wave
+// instruction = 32 rows; wave w fills rows 32w..32w+31 of all six plane tiles: 6 requests per wave and step), unpadded, the two 16-byte
+// chunks of a row XOR-swizzled by (row >> 3) & 1 on both sides so that a 16-lane ds_read_b128 group (rows r..r+15, one logical chunk)
+// covers all 16 sixteen-byte bank groups.  Three 24 KiB stages (72 KiB: two workgroups per CU), counted vmcnt(6), raw s_barrier.
+// Per step and wave: 12 ds_read_b128 for 24 MFMAs (each A / W fragment is used three times in registers) -- a third of the LDS bytes
+// per MFMA of a one-plane fp16 GEMM, which is what lets this loop run MFMA-bound where the fp16 kernels are LDS-bound.
+// WM = 32-row blocks per wave, NWC = wave columns (two wave rows always): <2, 2> is the 128x128 tile above (4 waves of 64x64, three
+// 24 KiB stages, two workgroups per CU); <4, 4> a 256x256 tile (8 waves of 128x64, three 48 KiB stages, one workgroup per CU);
+// <3, 4> a 192x256 tile (8 waves of 96x64, three 42 KiB stages).  The 128x128 form is bound by the L2 -> LDS feed (0.33 of the bf16
+// MFMA peak, the plateau of every 128x128 one-barrier GEMM on this part); the big tiles stage half the bytes per flop, and a step of
+// theirs is ~3000 MFMA cycles per SIMD, which also covers the DMA's ~1.5 us latency with two steps in flight.  192x256 exists for the
+// chip's 256 workgroup slots: M = 12000 gives 63 row tiles, so N = 1024 / 2048 / 3072 / 4096 make 252 / 504 / 756 / 1008 tiles = 0.98 /
+// 1.97 / 2.95 / 3.94 rounds, where 256x256 leaves a quarter of a round empty at N = 1024, 2048 and 3072.
+// DMA: a step is 3 x (BM / 32 + BN / 32) wave instructions of 1 KiB (32 rows of one plane tile); unit u goes to wave u % NW, so a
+// wave issues NU / NW requests per step -- 6, except 5 for waves 2..7 of the 192x256 form, whose counted waits differ accordingly.
+constexpr int X3_BK = 16;
+template <int WM, int NWC>
+__global__ __launch_bounds__(128 * NWC, WM == 2 ? 2 : 1) void gemm_x3_kernel(const GemmParams p) {
+    constexpr int STAGES = 3, AHEAD = 2;
+    constexpr int NW = 2 * NWC;                       // waves: 2 wave rows x NWC wave columns
+    constexpr int BM = 2 * WM * 32, BN = NWC * 64;
+    constexpr int ARB = BM / 32, WRB = BN / 32;       // 32-row blocks (= DMA instructions) per plane tile
+    constexpr int NU = 3 * (ARB + WRB);               // DMA units per step
+    constexpr int J = (NU + NW - 1) / NW;             // requests per wave and step (the last one only for waves < NU - (J - 1) * NW)
+    constexpr int LAST_WAVES = NU - (J - 1) * NW;     // waves that issue J requests (the others J - 1); == NW when NU % NW == 0
+    constexpr int A_TILE = BM * X3_BK, W_TILE = BN * X3_BK;          // bf16 elements of one plane tile
+    constexpr int STAGE = 3 * (A_TILE + W_TILE);
+    __shared__ __attribute__((aligned(1024))) __bf16 smem[STAGES * STAGE];   // [stage][A planes 0..2 | W planes 0..2][row * 16 + pos * 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr = wave / NWC, wc = wave % NWC;
+    // XCD-aware tile order (see gemm_f32_kernel)
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM, total = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = WM == 2 ? 8 : 4;
+    const int per_group = GROUP_M * nbx, g = bid / per_group;
+    const int gm = min(GROUP_M, nby - g * GROUP_M), in_g = bid - g * per_group;
+    const int by = g * GROUP_M + in_g % gm, bx = in_g / gm;
+    const int m0 = by * BM, n0 = bx * BN;
+
+    // DMA units of this wave: u = wave + NW * j; u < 3 * ARB: A plane u / ARB, row block u % ARB; else W plane (u - 3 ARB) / WRB, row block (..) % WRB.
+    // lane -> (row lane >> 1 of the 32-row block, chunk position lane & 1), source chunk pos ^ ((row >> 3) & 1)
+    const int r_local = lane >> 1, csrc = (lane & 1) ^ ((r_local >> 3) & 1);
+    unsigned uoff[J];          // per-lane BYTE offset of the unit's row inside its plane (32 bits: gemm_x3_usable checks the spans)
+    unsigned ulds[J];          // scalar: LDS byte offset of the unit inside a stage
+    long long ubase[J];        // scalar: byte offset of the unit's plane from p.A / p.W
+    bool u_is_a[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int u = wave + NW * j;
+        const bool is_a = u < 3 * ARB;
+        const int v = is_a ? u : u - 3 * ARB, rbn = is_a ? ARB : WRB;
+        const int pl = min(v / rbn, 2), rb = v % rbn;
+        const int row = rb * 32 + r_local;
+        u_is_a[j] = is_a;
+        if (is_a) {
+            const int m = min(m0 + row, p.M - 1);
+            const int bb = m / p.a_rows_per_batch;
+            uoff[j] = (unsigned)(((long long)bb * p.a_batch_stride + (long long)(m - bb * p.a_rows_per_batch) * p.lda + csrc * 8) * 2);
+            ulds[j] = (unsigned)((pl * A_TILE + rb * 32 * X3_BK) * 2);
+            ubase[j] = (long long)pl * p.a_plane * 2;
+        } else {
+            uoff[j] = (unsigned)(((long long)min(n0 + row, p.N - 1) * p.K + csrc * 8) * 2);
+            ulds[j] = (unsigned)((3 * A_TILE + pl * W_TILE + rb * 32 * X3_BK) * 2);
+            ubase[j] = (long long)pl * p.w_plane * 2;
+        }
+    }
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)(&smem[0]);
+    const bool last_unit = wave < LAST_WAVES;         // wave-uniform
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 on the clobber list: it is written and consumed inside the one statement
+    auto dma = [&](const int stage, const int kt) {
+        const unsigned st = lds_base + (unsigned)(stage * STAGE * 2);
+        const long long koff = (long long)kt * (X3_BK * 2);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (j == J - 1 && LAST_WAVES != NW && !last_unit) break;
+            const char* gb = reinterpret_cast<const char*>(u_is_a[j] ? p.A : p.W) + ubase[j] + koff;   // wave-uniform
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(__builtin_amdgcn_readfirstlane(st + ulds[j])), "v"(uoff[j]), "s"(gb) : "memory", "m0");
+        }
+    };
+#pragma clang diagnostic pop
+    // fragment reads (32x32x16: lane (r = l31, h = hh) holds row r, k = 8h .. 8h+7 = chunk h): position h ^ ((row >> 3) & 1); the row
+    // blocks start at multiples of 32, so (row >> 3) & 1 == (l31 >> 3) & 1 for every block
+    const int pos = (hh ^ ((l31 >> 3) & 1)) * 8;
+    const int ra = (wr * (WM * 32) + l31) * X3_BK + pos, rb = (wc * 64 + l31) * X3_BK + pos;
+
+    // accumulators of the wave tile's row blocks as NAMED arrays (one three-level array went to scratch: cdna guide rule 20):
+    // acc0 = row blocks 0, 1; acc1 = row blocks 2, 3 (WM == 4); acc2 = row block 2 (WM == 3)
+    f32x16 acc0[2][2], acc1[2][2], acc2[1][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[0][jj][r] = acc0[1][jj][r] = acc1[0][jj][r] = acc1[1][jj][r] = acc2[0][jj][r] = 0.f;
+
+    const int nk = p.K / X3_BK;
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    auto step = [&](auto CUR, const int kt) {
+        constexpr int cur = decltype(CUR)::value;
+        constexpr int fill = cur + AHEAD >= STAGES ? cur + AHEAD - STAGES : cur + AHEAD;   // the stage read during step kt-1
+        // this wave's share of step kt has landed (step kt+1's requests may be in flight: J of them, or J - 1)
+        if (kt + 1 < nk) {
+            if (LAST_WAVES == NW || last_unit) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(J) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(J - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();     // raw: __syncthreads() would add a vmcnt(0) fence and undo the counted wait
+        asm volatile("" ::: "memory");
+        const __bf16* As = smem + cur * STAGE;
+        const __bf16* Ws = As + 3 * A_TILE;
+        bf16x8 fa[WM][3], fb[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) fb[jj][pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * W_TILE + rb + jj * 32 * X3_BK);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) fa[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * A_TILE + ra + i * 32 * X3_BK);
+        }
+        if (kt + AHEAD < nk) dma(fill, kt + AHEAD);   // after the fragment reads are on their way
+        // six partial products per block, the small ones first
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                acc0[0][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[t]], fb[jj][PW[t]], acc0[0][jj], 0, 0, 0);
+                acc0[1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[t]], fb[jj][PW[t]], acc0[1][jj], 0, 0, 0);
+                if (WM == 3) acc2[0][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[WM - 1][PA[t]], fb[jj][PW[t]], acc2[0][jj], 0, 0, 0);
+                if (WM == 4) {
+                    acc1[0][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[WM - 2][PA[t]], fb[jj][PW[t]], acc1[0][jj], 0, 0, 0);
+                    acc1[1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[WM - 1][PA[t]], fb[jj][PW[t]], acc1[1][jj], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int kt = 0; kt < nk; kt += STAGES) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+        if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, kt + 2);
+    }
+    // the shared epilogues work on a wave's 64- (or 32-) row x 64-column pieces
+    gemm_epilogue_any<2>(p, acc0, m0 + wr * (WM * 32), n0 + wc * 64, 0, 0, l31, hh);
+    if (WM == 4) gemm_epilogue_any<2>(p, acc1, m0 + wr * (WM * 32) + 64, n0 + wc * 64, 0, 0, l31, hh);
+    if (WM == 3) gemm_epilogue_any<2, 1>(p, acc2, m0 + wr * (WM * 32) + 64, n0 + wc * 64, 0, 0, l31, hh);
+}
+
+bool gemm_x3_usable(const GemmParams& p) {
+    if (p.M <= 0 || p.N <= 0 || p.K < X3_BK || (p.K % X3_BK) || (p.lda & 7) || (p.a_batch_stride & 7) || p.a_rows_per_batch < 1 || p.c_rows_per_batch < 1) return false;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.a_plane & 7) || (p.w_plane & 7) || p.a_plane <= 0 || p.w_plane <= 0) return false;
+    const long long a_batches = (p.M + (long long)p.a_rows_per_batch - 1) / p.a_rows_per_batch;
+    const long long a_span = ((a_batches - 1) * (p.a_batch_stride > 0 ? p.a_batch_stride : 0) + (long long)p.a_rows_per_batch * p.lda + p.K) * 2;
+    return a_span < (1ll << 32) && (long long)p.N * p.K * 2 < (1ll << 32) && p.a_batch_stride >= 0 && p.lda >= 0;
+}
+
+hipError_t launch_gemm_x3(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipSuccess;
+    if (!gemm_x3_usable(p)) return hipErrorInvalidValue;
+    if (p.out_split && (p.epi != EPI_ROWMAJOR || p.c_plane <= 0)) return hipErrorInvalidValue;
+    {   // the fast epilogue indexes C / resid / pos with 32-bit element offsets (as launch_gemm_f32)
+        const long long batches = (p.M + (long long)p.c_rows_per_batch - 1) / p.c_rows_per_batch + 1;
+        const long long reach = p.epi == EPI_KV_HEADS
+                                    ? batches * p.kv_heads * p.kv_cap * HEAD_DIM + ((long long)p.c_rows_per_batch + p.kv_seq_off) * HEAD_DIM
+                                    : batches * (p.c_batch_stride > 0 ? p.c_batch_stride : 0) + ((long long)p.c_rows_per_batch + 1) * p.ldc + p.N;
+        const long long pos_reach = ((long long)p.c_rows_per_batch + 1) * p.N;
+        p.epi_fits32 = reach < (1ll << 31) && pos_reach < (1ll << 31) && p.c_batch_stride >= 0 && p.ldc >= 0;
+    }
+    // tile shape.  128x128: two 4-wave workgroups per CU (512 slots), L2-feed-bound; 256x256 and 192x256: one 8-wave workgroup per CU
+    // (256 slots), about twice as efficient per flop.  Estimated time = rounds of the chip x work per tile / efficiency; A/B:
+    // WT_GEMM_X3_TILE=128|192|256
+    static const int force_tile = tuning_env("WT_GEMM_X3_TILE") ? atoi(tuning_env("WT_GEMM_X3_TILE")) : 0;
+    const long long t128 = (long long)((p.N + 127) / 128) * ((p.M + 127) / 128), t256 = (long long)((p.N + 255) / 256) * ((p.M + 255) / 256),
+                    t192 = (long long)((p.N + 255) / 256) * ((p.M + 191) / 192);
+    // measured per round of the chip at K = 1024, M = 12000 (tools/microbench.py gemm_x3): 256x256 157 us, 192x256 142 us, 128x128 109 us
+    const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost192 = (double)((t192 + 255) / 256) * 0.905, cost128 = (double)((t128 + 511) / 512) * 0.695;
+    int tile = force_tile;
+    if (tile != 128 && tile != 192 && tile != 256) tile = (p.M < 192 || p.N < 256) ? 128 : (cost256 <= cost192 && cost256 <= cost128) ? 256 : cost192 <= cost128 ? 192 : 128;
+    if (tile == 256) hipLaunchKernelGGL((gemm_x3_kernel<4, 4>), dim3((unsigned)t256), dim3(512), 0, s, p);
+    else if (tile == 192) hipLaunchKernelGGL((gemm_x3_kernel<3, 4>), dim3((unsigned)t192), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_x3_kernel<2, 2>), dim3((unsigned)t128), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// fp32 [n] -> three bf16 planes (weights at engine open, the encoder memory in front of the cross-K/V projection)
+__global__ __launch_bounds__(256) void split3_kernel(const float4* __restrict__ x, __bf16* __restrict__ out, const size_t n4, const size_t plane) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x[i];
+        bf16x4 o1, o2, o3;
+        __bf16 a, b, c;
+        split3(v.x, a, b, c); o1[0] = a; o2[0] = b; o3[0] = c;
+        split3(v.y, a, b, c); o1[1] = a; o2[1] = b; o3[1] = c;
+        split3(v.z, a, b, c); o1[2] = a; o2[2] = b; o3[2] = c;
+        split3(v.w, a, b, c); o1[3] = a; o2[3] = b; o3[3] = c;
+        *reinterpret_cast<bf16x4*>(out + 4 * i) = o1;
+        *reinterpret_cast<bf16x4*>(out + plane + 4 * i) = o2;
+        *reinterpret_cast<bf16x4*>(out + 2 * plane + 4 * i) = o3;
+    }
+}
+hipError_t launch_split3(const float* x, void* planes, size_t n, size_t plane_stride, hipStream_t s) {
+    if ((n & 3) || (plane_stride & 3) || ((uintptr_t)x & 15) || ((uintptr_t)planes & 7)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    const size_t n4 = n >> 2;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<__bf16*>(planes), n4, plane_stride);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ encoder attention
 // softmax(Q K^T / 8) V per (utterance, head), S = 1500 keys, head_dim 64, no mask (layers/attention.py:308,
 // 337-345; HF :569-593).  Flash-style: scores never leave registers.  One workgroup = 128 queries (4 waves x 32),
@@ -648,8 +915,10 @@ constexpr int FA_SMEM = 2 * 2 * FA_BKV * FA_LD * (int)sizeof(float);  // 69,632 
 // SIMD allow, and skipping the MFMAs of waves / half tiles that lie entirely in the 1500 -> 1536 padding.  None moved it: the LDS is
 // not the limit (SQ_WAIT_INST_LDS 1.4 % of the wave cycles, no bank conflicts: profiles/r04_enc_attn_pmc_counters.txt), and a wave's
 // spare MFMA time goes nowhere while its workgroup waits for its slowest wave at the per-tile barrier.  DESIGN.md section 9 has the reading.
+// SPLIT: the context goes out as three bf16 planes (`ctx` = plane 0), the A operand of the out-projection's launch_gemm_x3
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int S,
-                                                          int H) {
+                                                          int H, size_t plane) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     // XCD-aware order (1-D grid; workgroup L runs on XCD L % 8): the query blocks of one (utterance, head) go to ONE XCD, back to back, so
@@ -822,13 +1091,34 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
 #undef FA_LSTORE
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
     if (qrow < S) {
-        float* op = ctx + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
+        const size_t at = ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
+        if (SPLIT) {
+            __bf16* op = reinterpret_cast<__bf16*>(ctx) + at;
+            auto put = [&](__bf16* dst, const float x0, const float x1, const float x2, const float x3) {
+                bf16x4 p1, p2, p3;
+                __bf16 b1, b2, b3;
+                split3(x0, b1, b2, b3); p1[0] = b1; p2[0] = b2; p3[0] = b3;
+                split3(x1, b1, b2, b3); p1[1] = b1; p2[1] = b2; p3[1] = b3;
+                split3(x2, b1, b2, b3); p1[2] = b1; p2[2] = b2; p3[2] = b3;
+                split3(x3, b1, b2, b3); p1[3] = b1; p2[3] = b2; p3[3] = b3;
+                *reinterpret_cast<bf16x4*>(dst) = p1;
+                *reinterpret_cast<bf16x4*>(dst + plane) = p2;
+                *reinterpret_cast<bf16x4*>(dst + 2 * plane) = p3;
+            };
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<float4*>(op + 8 * g) =
-                make_float4(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            *reinterpret_cast<float4*>(op + 32 + 8 * g) =
-                make_float4(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            for (int g = 0; g < 4; ++g) {
+                put(op + 8 * g, o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                put(op + 32 + 8 * g, o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            }
+        } else {
+            float* op = ctx + at;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(op + 8 * g) =
+                    make_float4(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + 32 + 8 * g) =
+                    make_float4(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            }
         }
     }
 }
@@ -836,21 +1126,26 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
 // workgroups of the attention kernel the runtime places on one CU (2: LDS admits two; checked on the box in round 4)
 int encoder_attention_blocks_per_cu() {
     int n = -1;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_attn_kernel, 256, FA_SMEM) != hipSuccess) return -1;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_attn_kernel<false>, 256, FA_SMEM) != hipSuccess) return -1;
     return n;
 }
 
-hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s) {
+hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s, void* ctx_planes, size_t plane_stride) {
     static PerDeviceFlag attr_set;
     if (!attr_set.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FA_SMEM);
         if (e != hipSuccess) return e;
         attr_set.set();
     }
     dim3 grid(((S + FA_BQ - 1) / FA_BQ) * H * B);
-    hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(256), FA_SMEM, s, qkv, ctx, S, H);
+    if (ctx_planes) {
+        if ((plane_stride & 3) || ((uintptr_t)ctx_planes & 7)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(enc_attn_kernel<true>, grid, dim3(256), FA_SMEM, s, qkv, reinterpret_cast<float*>(ctx_planes), S, H, plane_stride);
+    } else {
+        hipLaunchKernelGGL(enc_attn_kernel<false>, grid, dim3(256), FA_SMEM, s, qkv, ctx, S, H, (size_t)0);
+    }
     return hipGetLastError();
 }
 

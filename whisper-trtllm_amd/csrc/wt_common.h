@@ -59,6 +59,11 @@ struct GemmParams {
     int epi;              // 0 row-major, 1 split into K/V head caches [b][h][s_cap][64]
     int kv_heads, kv_cap, kv_seq_off;  // EPI_KV_HEADS: heads per row, cache capacity (rows), first row to write
     int epi_fits32;                    // set by launch_gemm_f32: every output / residual / position offset fits an int (fast epilogue)
+    // launch_gemm_x3 (fp32 product on the bf16 matrix cores, exactly split operands): A and W point at plane 0 of THREE bf16 planes with
+    // the fp32 operand's row layout (lda / a_batch_stride / K in ELEMENTS as usual), plane p at + p * a_plane / w_plane elements
+    long long a_plane, w_plane;
+    int out_split;                     // the epilogue writes C as three bf16 planes (row layout as C, plane p at + p * c_plane elements)
+    long long c_plane;
     long long* dbg_stamps;             // probe builds only (wt_dbg_gemm_stamps): [tiles][8] placement + wall-clock stamps per workgroup
 };
 enum { EPI_ROWMAJOR = 0, EPI_KV_HEADS = 1 };
@@ -171,7 +176,17 @@ struct DeviceGuard {
 hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels, int frames, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s);
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
-hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s);
+// ---- fp32 GEMM on the bf16 matrix cores.  x = b1 + b2 + b3 with bf16 b1 = rn(x), b2 = rn(x - b1), b3 = rn(x - b1 - b2) represents an fp32
+// value to 2^-27 relative (three 8-bit significands cover fp32's 24 bits; bf16 has fp32's exponent range), and a product a.w is the sum of
+// the six partial products a_i.w_j with i + j <= 4 up to 3 x 2^-27 relative -- below the 2^-24 rounding of an fp32 FMA.  Every partial
+// product of two bf16 values is exact in the MFMA's fp32 accumulator, which accumulates as the fp32 MFMA does.  Six
+// v_mfma_f32_32x32x16_bf16 replace sixteen v_mfma_f32_32x32x2_f32 per 32x32x16 block: 16 / 6 = 2.7x the fp32 MFMA peak.
+hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
+bool gemm_x3_usable(const GemmParams& p);   // shape / alignment limits of launch_gemm_x3 (else: launch_gemm_f32 on the fp32 operands)
+hipError_t launch_split3(const float* x, void* planes, size_t n, size_t plane_stride, hipStream_t s);   // fp32 [n] -> three bf16 planes
+hipError_t launch_layernorm_split(const float* x, const float* w, const float* b, void* planes, size_t plane_stride, int rows, int d, hipStream_t s);
+hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s, void* ctx_planes = nullptr, size_t plane_stride = 0);
+    // ctx_planes != nullptr: the context goes out as three bf16 planes (the A operand of launch_gemm_x3) instead of fp32 `ctx`
 int encoder_attention_blocks_per_cu();
 // fp16-encoder path (kernels_encoder_f16.hip): `void*` operands are __half buffers
 hipError_t launch_mel_transpose_h(const float* mel, void* melT, int B, int n_mels, int frames, hipStream_t s);
