@@ -415,7 +415,9 @@ def main():
                                        "useful_fp32_tflops": round(gemm_tf, 2), "fp32_mfma_peak": MFMA_F32_PEAK_TF, "useful_vs_fp32_mfma_peak": round(gemm_tf / MFMA_F32_PEAK_TF, 4),
                                        "launches": int(n_gemm), "total_ms": round(ms_gemm, 3),
                                        "enc_attn_tflops": round(attn_flop / (ms_eattn * 1e-3) / 1e12, 2) if ms_eattn > 0 else None,
-                                       "enc_attn_total_ms": round(ms_eattn, 3), "enc_attn_kernel": "enc_attn_kernel (v_mfma_f32_32x32x2_f32), peak 157.3"}
+                                       "enc_attn_total_ms": round(ms_eattn, 3),
+                                       "enc_attn_kernel": "enc_attn_kernel (v_mfma_f32_32x32x2_f32)" if (os.environ.get("WT_TUNING") == "1" and os.environ.get("WT_ATTN_X3") == "0")
+                                                          else "enc_attn_x3_kernel (both products as 6 bf16 MFMAs of exactly split operands, fp32 scores / softmax / accumulators); enc_attn_tflops = useful fp32 flops"}
         else:
             out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma4_kernel / gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
                                        "achieved": round(gemm_tf, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(gemm_tf / enc_peak, 4),

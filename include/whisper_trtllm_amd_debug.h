@@ -38,6 +38,8 @@ int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const fl
 int wt_dbg_encoder_attention_occupancy(void);   /* workgroups of enc_attn_kernel per CU as the runtime computes it */
 int wt_dbg_gemm_x3(const float* A, const float* W, const float* bias, const float* resid, void* C, int M, int N, int K, int act,
                    void* a_planes, void* w_planes, int flags, void* stream);   /* fp32 GEMM from bf16 MFMAs of exactly split operands; flags: 1 three-plane output, 2 planes already split */
+int wt_dbg_encoder_attention_split(const float* qkv, void* ctx_planes, int B, int S, int H, void* stream);   /* context as three bf16 planes [3][B*S][H*64] */
+int wt_dbg_encoder_attention_x3(const float* qkv, void* qkv_planes, void* ctx_planes, int B, int S, int H, int skip_split, void* stream);
 int wt_dbg_skinny_gelu_in(const float* X, const float* r, const float* t, const float* W, const float* bias, const float* resid, float* Y,
                           int B, int N, int K, void* stream);   /* probe: timing only */
 int wt_dbg_decode_attention(const float* q, const float* kcache, const float* vcache, float* part, int* cnt, float* out,

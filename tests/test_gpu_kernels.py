@@ -301,6 +301,51 @@ def test_encoder_attention(lib, B, S, H, scale):
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,S,H,scale", [(1, 64, 1, 1.0), (2, 96, 2, 1.0), (1, 1500, 2, 1.0), (2, 160, 3, 4.0), (1, 129, 1, 1.0),
+                                         (1, 200, 1, 30.0)])
+def test_encoder_attention_x3_is_an_fp32_attention(lib, B, S, H, scale):
+    """enc_attn_x3_kernel: both products of the attention formed on the bf16 matrix cores from exactly split operands (q, k, v planes in,
+    probabilities split in registers), fp32 scores / softmax / accumulators.  The same cases and the same bar as the fp32-MFMA kernel
+    (3e-5 of the output range, incl. a late running-max jump at scores in the thousands), and its error within 2x of that kernel's."""
+    d = 64 * H
+    qkv = _rand(B * S, 3 * d, seed=8, scale=scale)
+    if scale >= 30.0:
+        qkv[5, :64] = 6.0
+        qkv[S - 3, d:d + 64] = 6.0
+    qkv_d = qkv.cuda()
+    qkv_pl = torch.empty(3 * B * S * 3 * d, dtype=torch.bfloat16, device="cuda")
+    ctx_pl = torch.empty(3, B * S, d, dtype=torch.bfloat16, device="cuda")
+    ctx = torch.empty(B * S, d, device="cuda")
+    assert lib.wt_dbg_encoder_attention_x3(P(qkv_d), P(qkv_pl), P(ctx_pl), B, S, H, 0, _stream()) == 0
+    assert lib.wt_dbg_encoder_attention(P(qkv_d), P(ctx), B, S, H, _stream()) == 0
+    torch.cuda.synchronize()
+    t = qkv.double().view(B, S, 3, H, 64)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * S, d)
+    got = ctx_pl.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    err, err_native = (got - ref).abs().max().item(), (ctx.cpu().double() - ref).abs().max().item()
+    print(f"enc_attn_x3 B={B} S={S} H={H} scale={scale}: |err| {err:.2e} (fp32-MFMA kernel {err_native:.2e}, range {ref.abs().max().item():.1f})")
+    bar = 3e-5 * max(1.0, ref.abs().max().item())
+    assert err < bar
+    assert err <= 2.0 * err_native + 0.1 * bar
+
+
+def test_encoder_attention_three_plane_output_equals_the_fp32_output(lib):
+    """The x3 encoder path takes the attention context as three bf16 planes (the out-projection's A operand): b1 + b2 + b3 must equal the
+    fp32 context of the plain kernel to 2^-24 of each element (the same arithmetic, only the stores differ)."""
+    B, S, H = 2, 333, 3
+    d = 64 * H
+    qkv = _rand(B * S, 3 * d, seed=8).cuda()
+    ctx = torch.empty(B * S, d, device="cuda")
+    planes = torch.empty(3, B * S, d, dtype=torch.bfloat16, device="cuda")
+    assert lib.wt_dbg_encoder_attention(P(qkv), P(ctx), B, S, H, _stream()) == 0
+    assert lib.wt_dbg_encoder_attention_split(P(qkv), P(planes), B, S, H, _stream()) == 0
+    torch.cuda.synchronize()
+    got, want = planes.double().sum(0), ctx.double()
+    assert ((got - want).abs() <= want.abs() * 2.0 ** -24).all()
+
+
 @pytest.mark.parametrize("B,S,H,scale", [(1, 64, 1, 1.0), (2, 96, 2, 1.0), (1, 1500, 2, 1.0), (2, 160, 3, 3.0), (1, 129, 1, 1.0), (1, 200, 1, 12.0)])
 def test_encoder_attention_f16(lib, B, S, H, scale):
     d = 64 * H

@@ -356,6 +356,13 @@ def bench_enc_attn(B=8, S=1500, H=16):
     ctx = torch.empty(B * S, 64 * H, device="cuda")
     us = timeit(lambda i: lib.wt_dbg_encoder_attention(P(qkv), P(ctx), B, S, H, ST()), 1, iters=5)
     print(f"enc_attn B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")
+    planes = torch.empty(3, B * S, 64 * H, dtype=torch.bfloat16, device="cuda")
+    us = timeit(lambda i: lib.wt_dbg_encoder_attention_split(P(qkv), P(planes), B, S, H, ST()), 1, iters=5)
+    print(f"enc_attn (context out as three bf16 planes) B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")
+    qkv_pl = torch.empty(3 * B * S * 3 * 64 * H, dtype=torch.bfloat16, device="cuda")
+    lib.wt_dbg_encoder_attention_x3(P(qkv), P(qkv_pl), P(planes), B, S, H, 0, ST())
+    us = timeit(lambda i: lib.wt_dbg_encoder_attention_x3(P(qkv), P(qkv_pl), P(planes), B, S, H, 1, ST()), 1, iters=5)
+    print(f"enc_attn_x3 (q|k|v planes in, context planes out) B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s useful")
     qkv_h, ctx_h = qkv.half(), ctx.half()
     us = timeit(lambda i: lib.wt_dbg_encoder_attention_f16(P(qkv_h), P(ctx_h), B, S, H, ST()), 1, iters=5)
     print(f"enc_attn_f16 B={B} S={S} H={H}: {us:8.1f} us  {4.0 * B * H * S * S * 64 / us * 1e-6:6.1f} TFLOP/s")

@@ -21,7 +21,7 @@ EXPORTS = [
     "wt_engine_set_profiling", "wt_engine_get_timer", "wt_decoder_time_cross_attention", "wt_decoder_time_kernel",
     "wt_logmel_create", "wt_logmel_destroy", "wt_logmel_forward", "wt_last_error", "wt_abi_version",
 ]
-DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_x3", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_skinny_gelu_in", "wt_dbg_encoder_attention_occupancy", "wt_dbg_decode_attention",
+DEBUG_EXPORTS = ["wt_dbg_gemm", "wt_dbg_gemm_x3", "wt_dbg_gemm_stamps", "wt_dbg_gemm_f16", "wt_dbg_gemm_f16_variant", "wt_dbg_layernorm", "wt_dbg_encoder_attention", "wt_dbg_encoder_attention_split", "wt_dbg_encoder_attention_x3", "wt_dbg_encoder_attention_f16", "wt_dbg_skinny", "wt_dbg_skinny_gelu_in", "wt_dbg_encoder_attention_occupancy", "wt_dbg_decode_attention",
                  "wt_dbg_decode_attention_folded", "wt_dbg_skinny_pair", "wt_dbg_attention_then_projection", "wt_dbg_self_attention_then_pair",
                  "wt_dbg_skinny_f16", "wt_dbg_decode_attention_f16", "wt_dbg_attention_then_projection_f16", "wt_dbg_skinny_pair_f16", "wt_dbg_gemm_f16_kv"]
 
@@ -113,6 +113,8 @@ def load():
     lib.wt_dbg_gemm_f16_variant.argtypes = [P, I, P, P, P, P, I, I, I, I, I, I, P]
     lib.wt_dbg_layernorm.argtypes = [P, P, P, P, I, I, P]
     lib.wt_dbg_encoder_attention.argtypes = [P, P, I, I, I, P]
+    lib.wt_dbg_encoder_attention_split.argtypes = [P, P, I, I, I, P]
+    lib.wt_dbg_encoder_attention_x3.argtypes = [P, P, P, I, I, I, I, P]
     lib.wt_dbg_encoder_attention_f16.argtypes = [P, P, I, I, I, P]
     lib.wt_dbg_skinny.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, F, P]
     lib.wt_dbg_skinny_gelu_in.argtypes = [P, P, P, P, P, P, P, I, I, I, P]

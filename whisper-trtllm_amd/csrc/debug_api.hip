@@ -49,6 +49,16 @@ extern "C" int wt_dbg_encoder_attention(const float* qkv, float* ctx, int B, int
     return rc_of(launch_encoder_attention(qkv, ctx, B, S, H, (hipStream_t)stream));
 }
 extern "C" int wt_dbg_encoder_attention_occupancy(void) { return encoder_attention_blocks_per_cu(); }
+extern "C" int wt_dbg_encoder_attention_split(const float* qkv, void* ctx_planes, int B, int S, int H, void* stream) {
+    return rc_of(launch_encoder_attention(qkv, nullptr, B, S, H, (hipStream_t)stream, ctx_planes, (size_t)B * S * H * 64));
+}
+// x3 attention: the hook splits fp32 q|k|v [B*S][3d] into the caller's scratch planes (3 * B*S * 3d bf16) and attends; context out as planes
+extern "C" int wt_dbg_encoder_attention_x3(const float* qkv, void* qkv_planes, void* ctx_planes, int B, int S, int H, int skip_split, void* stream) {
+    const size_t n = (size_t)B * S * 3 * H * 64;
+    int rc = skip_split ? 0 : rc_of(launch_split3(qkv, qkv_planes, n, n, (hipStream_t)stream));
+    if (rc) return rc;
+    return rc_of(launch_encoder_attention_x3(qkv_planes, n, ctx_planes, (size_t)B * S * H * 64, B, S, H, (hipStream_t)stream));
+}
 extern "C" int wt_dbg_skinny(const float* X, const float* ln_w, const float* ln_b, const float* W, const float* bias,
                              const float* resid, float* Y, int B, int N, int K, int xmode, int act, float scale,
                              void* stream) {

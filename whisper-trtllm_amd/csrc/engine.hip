@@ -94,7 +94,7 @@ struct wt_engine {
     char* enc_ws = nullptr;
     float *melT = nullptr, *c1 = nullptr, *hbuf = nullptr, *xbuf = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
     bool use_x3 = false;          // fp32 engine: the layer GEMMs / the cross-K/V projection run launch_gemm_x3 (fp32 product from bf16 MFMAs)
-    void *xs3 = nullptr, *ctx3 = nullptr, *ffn3 = nullptr;   // x3 activations: three bf16 planes of [M][d] / [M][d] / [M][F]
+    void *xs3 = nullptr, *ctx3 = nullptr, *ffn3 = nullptr, *qkv3 = nullptr;   // x3 activations: three bf16 planes of [M][d] / [M][d] / [M][F] / [M][3d]
     void* enc3 = nullptr;         // decoder: three bf16 planes of the encoder memory in front of the cross-K/V projection
     void *melT_h = nullptr, *c1_h = nullptr, *x_h = nullptr, *ctx_h = nullptr, *ffn_h = nullptr;  // fp16 engines
     // decoder
@@ -436,13 +436,14 @@ static int enc_reserve(wt_engine* e, int B, hipStream_t s) {
     const size_t o_h = take(M * d), o_x = take(M * d), o_qkv = take(M * 3 * d), o_ctx = take(M * d), o_ffn = take(M * e->F);
     // x3 GEMMs: their A operands as three bf16 planes (6 bytes per element = 1.5 floats)
     const size_t o_xs3 = take(e->use_x3 ? (M * d * 3 + 1) / 2 : 0), o_ctx3 = take(e->use_x3 ? (M * d * 3 + 1) / 2 : 0), o_ffn3 = take(e->use_x3 ? (M * e->F * 3 + 1) / 2 : 0);
+    const size_t o_qkv3 = take(e->use_x3 ? (M * 3 * d * 3 + 1) / 2 : 0);
     // fp16 engines reuse the fp32-sized regions for their half-precision activations (half the bytes)
     hipError_t he = hipMalloc((void**)&e->enc_ws, off);
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for encoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
     e->melT = (float*)(e->enc_ws + o_melT); e->c1 = (float*)(e->enc_ws + o_c1); e->hbuf = (float*)(e->enc_ws + o_h);
     e->xbuf = (float*)(e->enc_ws + o_x); e->qkv = (float*)(e->enc_ws + o_qkv); e->ctx = (float*)(e->enc_ws + o_ctx);
     e->ffn = (float*)(e->enc_ws + o_ffn);
-    e->xs3 = e->enc_ws + o_xs3; e->ctx3 = e->enc_ws + o_ctx3; e->ffn3 = e->enc_ws + o_ffn3;
+    e->xs3 = e->enc_ws + o_xs3; e->ctx3 = e->enc_ws + o_ctx3; e->ffn3 = e->enc_ws + o_ffn3; e->qkv3 = e->enc_ws + o_qkv3;
     e->melT_h = e->melT; e->c1_h = e->c1; e->x_h = e->xbuf; e->ffn_h = e->ffn;
     e->ctx_h = (char*)e->ffn + M * e->F * 2;  // second half of the ffn region (M*F*2 bytes >= M*d*2)
     // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
@@ -572,11 +573,13 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
         for (int i = 0; i < e->L; ++i) {
             const EncLayerW& l = e->enc_layers[i];
             LAUNCH(launch_layernorm_split(e->hbuf, l.ln1_w, l.ln1_b, e->xs3, pl_d, M, d, s));
-            if ((rc = dense3(e->xs3, d, l.qkv_w3, l.qkv_b, 3 * d, e->qkv, 0, nullptr, false))) return rc;
+            static const bool attn_x3 = !(tuning_env("WT_ATTN_X3") && atoi(tuning_env("WT_ATTN_X3")) == 0);   // A/B switch: fp32-MFMA attention
+            if ((rc = dense3(e->xs3, d, l.qkv_w3, l.qkv_b, 3 * d, attn_x3 ? e->qkv3 : (void*)e->qkv, 0, nullptr, attn_x3))) return rc;
             {
                 hipEvent_t a, b;
                 timer_begin(e, e->t_enc_attn, s, &a, &b);
-                LAUNCH(launch_encoder_attention(e->qkv, nullptr, B, S, e->H, s, e->ctx3, pl_d));
+                if (attn_x3) LAUNCH(launch_encoder_attention_x3(e->qkv3, (size_t)M * 3 * d, e->ctx3, pl_d, B, S, e->H, s));
+                else LAUNCH(launch_encoder_attention(e->qkv, nullptr, B, S, e->H, s, e->ctx3, pl_d));
                 timer_end(e, e->t_enc_attn, s, a, b);
             }
             if ((rc = dense3(e->ctx3, d, l.o_w3, l.o_b, d, e->hbuf, 0, e->hbuf, false))) return rc;

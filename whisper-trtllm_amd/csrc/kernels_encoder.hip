@@ -307,6 +307,7 @@ __device__ __forceinline__ void gemm_epilogue_any(const GemmParams& p, const f32
     const bool interior = m0 + wr * 64 + 32 * TI <= p.M && n0 + wc * (32 * TJ) + 32 * TJ <= p.N && p.c_rows_per_batch >= 64 && p.epi_fits32;
     if (p.out_split) {   // three bf16 planes out (the A operand of the next launch_gemm_x3): fc1's GELU output
         if (interior && p.epi == EPI_ROWMAJOR && !p.pos && !p.resid && p.act) return gemm_epilogue_fast<false, true, false, false, TJ, true, TI>(p, acc, m0, n0, wr, wc, l31, hh);
+        if (interior && p.epi == EPI_ROWMAJOR && !p.pos && !p.resid && !p.act) return gemm_epilogue_fast<false, false, false, false, TJ, true, TI>(p, acc, m0, n0, wr, wc, l31, hh);
         return gemm_epilogue<TJ, TI>(p, acc, m0, n0, wr, wc, l31, hh);
     }
     if (interior && p.epi == EPI_ROWMAJOR && !p.pos) {
@@ -1121,6 +1122,208 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ encoder attention, x3 form
+// The same flash-style kernel with BOTH products formed like launch_gemm_x3's: q, k, v arrive as three bf16 planes each (the q|k|v GEMM's
+// epilogue writes them), the probabilities are split in registers, every 32x32x16 block is six v_mfma_f32_32x32x16_bf16 into the fp32
+// accumulators (a3.b1, a1.b3, a2.b2, a2.b1, a1.b2, a1.b1), scores / softmax / accumulators stay fp32.  96 bf16 MFMAs of 32 cycles per
+// 64-key tile and wave instead of 128 fp32 MFMAs of 64 cycles.  Transposed formulation as above:
+//   S^T[key][query] = K . Q^T   (A = K rows from LDS, B = the wave's Q rows, held in registers for the whole kernel)
+//   O^T[dv][query] += V^T . P^T (B = P straight from the S^T accumulator registers: registers 8t .. 8t+7 are k-step t, whose key order
+//                                16t + 8 (j >> 2) + 4 h + (j & 3) is matched by reading V^T with the same permutation from a TRANSPOSED V
+//                                tile in LDS -- the scheme of enc_attn_f16_kernel).
+// LDS: one 64-key stage of 3 x (K [64][72] + V^T [64][68]) bf16 = 53,760 B (K rows padded to 144 B: conflict-free ds_read_b128; V^T rows
+// to 136 B: conflict-free ds_read_b64), single-buffered so that two workgroups share a CU: the next tile's global loads are issued before
+// the current tile's products and stored behind a second barrier.
+constexpr int XA_BQ = 128, XA_BKV = 64, XA_KLD = 72, XA_VLD = 68;                   // strides in bf16 elements
+constexpr int XA_PLANE = XA_BKV * XA_KLD + HEAD_DIM * XA_VLD;                        // one plane's (K, V^T) tile
+constexpr int XA_SMEM = 3 * XA_PLANE * 2;                                            // 53,760 B
+__global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ ctx, int S, int H,
+                                                             size_t in_plane, size_t out_plane) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xa_raw[];
+    __bf16* smem = reinterpret_cast<__bf16*>(xa_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    int b, h, q0;
+    {   // XCD-chunked head-major order, as in enc_attn_kernel: a head's K / V land in one L2 instead of eight
+        const int nqb = (S + XA_BQ - 1) / XA_BQ, total = (int)gridDim.x;
+        const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int bh = v / nqb;
+        b = bh / H; h = bh % H; q0 = (v - bh * nqb) * XA_BQ;
+    }
+    const int d = H * HEAD_DIM, ld = 3 * d;
+    const __bf16* base = qkv + (size_t)b * S * ld + h * HEAD_DIM;
+
+    const int qrow = q0 + wave * 32 + l31;
+    bf16x8 qf[3][4];   // plane p of Q[query][16 s + 8 h .. +7], pre-scaled by 64^-0.5 (a power of two: exact in every plane)
+    {
+        const __bf16* qp = base + (size_t)min(qrow, S - 1) * ld + 8 * hh;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qf[pl][s] = *reinterpret_cast<const bf16x8*>(qp + pl * in_plane + 16 * s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[pl][s][e] = (__bf16)((float)qf[pl][s][e] * 0.125f);
+            }
+    }
+    // staging: 64 keys x 8 sixteen-byte chunks per matrix and plane; thread -> chunk c8 (8 head dims), keys r0 and r0 + 32
+    const int c8 = tid & 7, r0 = tid >> 3;
+    const __bf16* gbase = base + c8 * 8;
+    bf16x8 rk[3][2], rv[3][2];
+    auto gload = [&](const int kv0) {
+        const __bf16* rp0 = gbase + (size_t)min(kv0 + r0, S - 1) * ld;
+        const __bf16* rp1 = gbase + (size_t)min(kv0 + r0 + 32, S - 1) * ld;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            rk[pl][0] = *reinterpret_cast<const bf16x8*>(rp0 + pl * in_plane + d);
+            rv[pl][0] = *reinterpret_cast<const bf16x8*>(rp0 + pl * in_plane + 2 * d);
+            rk[pl][1] = *reinterpret_cast<const bf16x8*>(rp1 + pl * in_plane + d);
+            rv[pl][1] = *reinterpret_cast<const bf16x8*>(rp1 + pl * in_plane + 2 * d);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            __bf16* Ks_ = smem + pl * XA_PLANE;
+            __bf16* Vt_ = Ks_ + XA_BKV * XA_KLD;
+            *reinterpret_cast<bf16x8*>(Ks_ + r0 * XA_KLD + c8 * 8) = rk[pl][0];
+            *reinterpret_cast<bf16x8*>(Ks_ + (r0 + 32) * XA_KLD + c8 * 8) = rk[pl][1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                Vt_[(c8 * 8 + e) * XA_VLD + r0] = rv[pl][0][e];
+                Vt_[(c8 * 8 + e) * XA_VLD + r0 + 32] = rv[pl][1][e];
+            }
+        }
+    };
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // the six partial products, the small ones first
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (S + XA_BKV - 1) / XA_BKV;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * XA_BKV;
+        if (t + 1 < ntiles) gload(kv0 + XA_BKV);
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 k0[3], k1[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const __bf16* kp = smem + pl * XA_PLANE + l31 * XA_KLD + 8 * hh + 16 * s;
+                k0[pl] = *reinterpret_cast<const bf16x8*>(kp);
+                k1[pl] = *reinterpret_cast<const bf16x8*>(kp + 32 * XA_KLD);
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0[PA[c]], qf[PB[c]][s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1[PA[c]], qf[PB[c]][s], s1, 0, 0, 0);
+            }
+        }
+        if (kv0 + XA_BKV > S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= S) s0[r] = -INFINITY;
+                if (key + 32 >= S) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __expf(s0[r] - m_new);
+            s1[r] = __expf(s1[r] - m_new);
+            ps += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        // P.V: k-step (kt, t2) covers keys kt*32 + 16*t2 .. +15; B fragment = accumulator registers 8*t2 .. 8*t2+7, split into three planes
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                bf16x8 pf[3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 b1, b2, b3;
+                    split3(kt == 0 ? s0[8 * t2 + j] : s1[8 * t2 + j], b1, b2, b3);
+                    pf[0][j] = b1; pf[1][j] = b2; pf[2][j] = b3;
+                }
+                const int kb = kt * 32 + 16 * t2;
+                bf16x8 va0[3], va1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const __bf16* vp = smem + pl * XA_PLANE + XA_BKV * XA_KLD + l31 * XA_VLD + 4 * hh + kb;
+                    const bf16x4 a00 = *reinterpret_cast<const bf16x4*>(vp), a01 = *reinterpret_cast<const bf16x4*>(vp + 8);
+                    const bf16x4 a10 = *reinterpret_cast<const bf16x4*>(vp + 32 * XA_VLD), a11 = *reinterpret_cast<const bf16x4*>(vp + 32 * XA_VLD + 8);
+                    va0[pl] = bf16x8{a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
+                    va1[pl] = bf16x8{a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0[PA[c]], pf[PB[c]], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1[PA[c]], pf[PB[c]], o1, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                 // every wave is done with this tile ...
+        if (t + 1 < ntiles) {
+            lstore();                    // ... the next one goes in (its loads were issued before the products)
+            __syncthreads();
+        }
+    }
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (qrow < S) {
+        __bf16* op = ctx + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
+        auto put = [&](__bf16* dst, const float x0, const float x1, const float x2, const float x3) {
+            bf16x4 p1, p2, p3;
+            __bf16 b1, b2, b3;
+            split3(x0, b1, b2, b3); p1[0] = b1; p2[0] = b2; p3[0] = b3;
+            split3(x1, b1, b2, b3); p1[1] = b1; p2[1] = b2; p3[1] = b3;
+            split3(x2, b1, b2, b3); p1[2] = b1; p2[2] = b2; p3[2] = b3;
+            split3(x3, b1, b2, b3); p1[3] = b1; p2[3] = b2; p3[3] = b3;
+            *reinterpret_cast<bf16x4*>(dst) = p1;
+            *reinterpret_cast<bf16x4*>(dst + out_plane) = p2;
+            *reinterpret_cast<bf16x4*>(dst + 2 * out_plane) = p3;
+        };
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            put(op + 8 * g, o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            put(op + 32 + 8 * g, o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+// q|k|v as three bf16 planes [3][B*S][3d] (plane stride in_plane elements) -> context as three bf16 planes [3][B*S][d]
+hipError_t launch_encoder_attention_x3(const void* qkv_planes, size_t in_plane, void* ctx_planes, size_t out_plane, int B, int S, int H, hipStream_t s) {
+    if ((in_plane & 7) || (out_plane & 3) || ((uintptr_t)qkv_planes & 15) || ((uintptr_t)ctx_planes & 7) || ((H * HEAD_DIM) & 7)) return hipErrorInvalidValue;
+    static PerDeviceFlag attr_set;
+    if (!attr_set.get()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_SMEM);
+        if (e != hipSuccess) return e;
+        attr_set.set();
+    }
+    dim3 grid(((S + XA_BQ - 1) / XA_BQ) * H * B);
+    hipLaunchKernelGGL(enc_attn_x3_kernel, grid, dim3(256), XA_SMEM, s, reinterpret_cast<const __bf16*>(qkv_planes), reinterpret_cast<__bf16*>(ctx_planes), S, H, in_plane, out_plane);
+    return hipGetLastError();
 }
 
 // workgroups of the attention kernel the runtime places on one CU (2: LDS admits two; checked on the box in round 4)

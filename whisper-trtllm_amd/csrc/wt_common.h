@@ -188,6 +188,8 @@ hipError_t launch_layernorm_split(const float* x, const float* w, const float* b
 hipError_t launch_encoder_attention(const float* qkv, float* ctx, int B, int S, int H, hipStream_t s, void* ctx_planes = nullptr, size_t plane_stride = 0);
     // ctx_planes != nullptr: the context goes out as three bf16 planes (the A operand of launch_gemm_x3) instead of fp32 `ctx`
 int encoder_attention_blocks_per_cu();
+// x3 form (both products from bf16 MFMAs of exactly split operands, fp32 scores / softmax / accumulators): q|k|v in, context out as planes
+hipError_t launch_encoder_attention_x3(const void* qkv_planes, size_t in_plane, void* ctx_planes, size_t out_plane, int B, int S, int H, hipStream_t s);
 // fp16-encoder path (kernels_encoder_f16.hip): `void*` operands are __half buffers
 hipError_t launch_mel_transpose_h(const float* mel, void* melT, int B, int n_mels, int frames, hipStream_t s);
 hipError_t launch_layernorm_h(const float* x, const float* w, const float* b, void* y, int rows, int d, hipStream_t s);
