@@ -81,6 +81,10 @@ struct WeightStore {
 };
 
 struct wt_engine {
+    const void *conv1_w3 = nullptr, *conv2_w3 = nullptr;   // conv weights as three bf16 planes (launch_gemm_x3)
+    void *melT3 = nullptr, *c1_3 = nullptr;                 // x3: the convs' A operands as three bf16 planes (time-major, zero pad rows)
+    size_t melT3_plane = 0, c1_3_plane = 0;                 // their plane strides: fixed by the workspace CAPACITY, so that a smaller batch finds
+                                                            // utterance b's rows -- and the zero padding rows nobody ever writes -- where a larger one left them
     int kind = 0, device = 0, precision = WT_F32;
     int d = 0, H = 0, L = 0, F = 0, C = 0, S = 0, T = 0, V = 0;
     std::shared_ptr<WeightStore> weights;
@@ -224,6 +228,10 @@ static int build_x3_weights(wt_engine* e) {
     const size_t d = e->d, F = e->F;
     struct Job { const float* src; size_t n; const void** dst; };
     std::vector<Job> jobs;
+    if (e->kind == WT_KIND_ENCODER && (e->C % 8) == 0 && ((3 * e->C) % 16) == 0) {
+        jobs.push_back({e->conv1_w, d * 3 * (size_t)e->C, &e->conv1_w3});
+        jobs.push_back({e->conv2_w, d * 3 * d, &e->conv2_w3});
+    }
     if (e->kind == WT_KIND_ENCODER)
         for (EncLayerW& l : e->enc_layers) {
             jobs.push_back({l.qkv_w, 3 * d * d, &l.qkv_w3}); jobs.push_back({l.o_w, d * d, &l.o_w3});
@@ -406,7 +414,7 @@ extern "C" int wt_engine_clone(const wt_engine* src, wt_engine** out) {
     e->enc_pos = src->enc_pos; e->enc_ln_w = src->enc_ln_w; e->enc_ln_b = src->enc_ln_b;
     e->dec_layers = src->dec_layers;
     e->tok_emb = src->tok_emb; e->pos_emb = src->pos_emb; e->proj_w = src->proj_w; e->dec_ln_w = src->dec_ln_w; e->dec_ln_b = src->dec_ln_b;
-    e->w_half = src->w_half; e->kv_esz = src->kv_esz; e->use_x3 = src->use_x3;
+    e->w_half = src->w_half; e->kv_esz = src->kv_esz; e->use_x3 = src->use_x3; e->conv1_w3 = src->conv1_w3; e->conv2_w3 = src->conv2_w3;
     // workspace, resident caches, step graphs, streams, mailbox, timers: this handle's own, allocated on first use like a fresh engine's
     *out = e;
     return WT_OK;
@@ -437,6 +445,8 @@ static int enc_reserve(wt_engine* e, int B, hipStream_t s) {
     // x3 GEMMs: their A operands as three bf16 planes (6 bytes per element = 1.5 floats)
     const size_t o_xs3 = take(e->use_x3 ? (M * d * 3 + 1) / 2 : 0), o_ctx3 = take(e->use_x3 ? (M * d * 3 + 1) / 2 : 0), o_ffn3 = take(e->use_x3 ? (M * e->F * 3 + 1) / 2 : 0);
     const size_t o_qkv3 = take(e->use_x3 ? (M * 3 * d * 3 + 1) / 2 : 0);
+    const size_t n_melT = (size_t)B * (Fr + 2) * e->C + 4 * e->C, n_c1 = (size_t)B * (Fr + 2) * d + 4 * d;   // elements per plane
+    const size_t o_melT3 = take(e->conv1_w3 ? (n_melT * 3 + 1) / 2 : 0), o_c1_3 = take(e->conv1_w3 ? (n_c1 * 3 + 1) / 2 : 0);
     // fp16 engines reuse the fp32-sized regions for their half-precision activations (half the bytes)
     hipError_t he = hipMalloc((void**)&e->enc_ws, off);
     if (he != hipSuccess) return fail(WT_E_NOMEM, "hipMalloc(%zu) for encoder workspace (batch %d) failed: %s", off, B, hipGetErrorString(he));
@@ -444,6 +454,12 @@ static int enc_reserve(wt_engine* e, int B, hipStream_t s) {
     e->xbuf = (float*)(e->enc_ws + o_x); e->qkv = (float*)(e->enc_ws + o_qkv); e->ctx = (float*)(e->enc_ws + o_ctx);
     e->ffn = (float*)(e->enc_ws + o_ffn);
     e->xs3 = e->enc_ws + o_xs3; e->ctx3 = e->enc_ws + o_ctx3; e->ffn3 = e->enc_ws + o_ffn3; e->qkv3 = e->enc_ws + o_qkv3;
+    e->melT3 = e->enc_ws + o_melT3; e->c1_3 = e->enc_ws + o_c1_3;
+    e->melT3_plane = n_melT; e->c1_3_plane = n_c1;
+    if (e->conv1_w3) {   // zero padding rows of the plane forms (a bf16 zero is all-zero bits)
+        HIPCHK(hipMemsetAsync(e->melT3, 0, n_melT * 6, s));
+        HIPCHK(hipMemsetAsync(e->c1_3, 0, n_c1 * 6, s));
+    }
     e->melT_h = e->melT; e->c1_h = e->c1; e->x_h = e->xbuf; e->ffn_h = e->ffn;
     e->ctx_h = (char*)e->ffn + M * e->F * 2;  // second half of the ffn region (M*F*2 bytes >= M*d*2)
     // conv zero-padding rows (row 0 / row F+1 of every utterance) are never written by the kernels below
@@ -530,8 +546,33 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
     if (rc) return rc;
     const int S = e->S, Fr = 2 * S, d = e->d, C = e->C, M = B * S;
     if (e->precision == WT_F16) return encoder_forward_f16(e, mel, B, out, s);
-    LAUNCH(launch_mel_transpose(mel, e->melT, B, C, Fr, s));
     GemmParams g;
+    bool convs_x3 = false;
+    if (e->use_x3 && e->conv1_w3) {   // both convolutions as launch_gemm_x3 (operand planes; conv1's GELU output goes out as planes for conv2)
+        const size_t n_melT = e->melT3_plane, n_c1 = e->c1_3_plane;
+        GemmParams c1g, c2g;
+        memset(&c1g, 0, sizeof c1g);
+        c1g.A = (const float*)e->melT3; c1g.lda = C; c1g.a_rows_per_batch = Fr; c1g.a_batch_stride = (long long)(Fr + 2) * C; c1g.a_plane = (long long)n_melT;
+        c1g.W = (const float*)e->conv1_w3; c1g.w_plane = (long long)d * 3 * C; c1g.bias = e->conv1_b; c1g.M = B * Fr; c1g.N = d; c1g.K = 3 * C; c1g.act = 1;
+        c1g.C = (float*)((char*)e->c1_3 + (size_t)d * 2); c1g.ldc = d; c1g.c_rows_per_batch = Fr; c1g.c_batch_stride = (long long)(Fr + 2) * d;
+        c1g.out_split = 1; c1g.c_plane = (long long)n_c1;
+        memset(&c2g, 0, sizeof c2g);
+        c2g.A = (const float*)e->c1_3; c2g.lda = 2 * d; c2g.a_rows_per_batch = S; c2g.a_batch_stride = (long long)(Fr + 2) * d; c2g.a_plane = (long long)n_c1;
+        c2g.W = (const float*)e->conv2_w3; c2g.w_plane = (long long)d * 3 * d; c2g.bias = e->conv2_b; c2g.M = M; c2g.N = d; c2g.K = 3 * d; c2g.act = 1; c2g.pos = e->enc_pos;
+        c2g.C = e->hbuf; c2g.ldc = d; c2g.c_rows_per_batch = S; c2g.c_batch_stride = (long long)S * d;
+        if (gemm_x3_usable(c1g) && gemm_x3_usable(c2g)) {
+            convs_x3 = true;
+            LAUNCH(launch_mel_transpose_split(mel, e->melT3, n_melT, B, C, Fr, s));
+            for (const GemmParams* q : {&c1g, &c2g}) {
+                hipEvent_t a, b;
+                timer_begin(e, e->t_gemm, s, &a, &b);
+                LAUNCH(launch_gemm_x3(*q, s));
+                timer_end(e, e->t_gemm, s, a, b);
+            }
+        }
+    }
+    if (!convs_x3) {
+    LAUNCH(launch_mel_transpose(mel, e->melT, B, C, Fr, s));
     memset(&g, 0, sizeof g);
     // conv1 (k=3, pad 1) + GELU as an implicit GEMM over the time-major padded mel (model.py:78,97)
     g.A = e->melT; g.lda = C; g.a_rows_per_batch = Fr; g.a_batch_stride = (long long)(Fr + 2) * C;
@@ -544,6 +585,7 @@ extern "C" int wt_encoder_forward(wt_engine* e, const float* mel, int B, float* 
     g.W = e->conv2_w; g.bias = e->conv2_b; g.M = M; g.N = d; g.K = 3 * d; g.act = 1; g.pos = e->enc_pos;
     g.C = e->hbuf; g.ldc = d; g.c_rows_per_batch = S; g.c_batch_stride = (long long)S * d;
     if ((rc = timed_gemm(e, g, s))) return rc;
+    }
 
     auto dense = [&](const float* A, int K, const float* Wt, const float* bias, int N, float* Cout, int act,
                      const float* resid) {

@@ -38,8 +38,10 @@ __device__ __forceinline__ void store_split3(float* base, const long long off, c
 // ------------------------------------------------------------------------------------------------ mel transpose
 // mel [B][C][F] (time contiguous, the layout of run.py's `input_features`) -> melT [B][F+2][C], row = time+1,
 // rows 0 and F+1 are the conv zero padding (written here).  Makes conv1 an implicit GEMM with K = 3*C, lda = C.
+// SPLIT: melT goes out as three bf16 planes (conv1's A operand for launch_gemm_x3; plane p at + p * plane elements)
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void mel_transpose_kernel(const float* __restrict__ mel, float* __restrict__ melT,
-                                                            int C, int F) {
+                                                            int C, int F, size_t plane) {
     __shared__ float tile[128][65];
     const int b = blockIdx.y, t0 = blockIdx.x * 64;
     for (int i = threadIdx.x; i < C * 64; i += 256) {
@@ -47,6 +49,25 @@ __global__ __launch_bounds__(256) void mel_transpose_kernel(const float* __restr
         tile[c][tl] = t < F ? mel[((size_t)b * C + c) * F + t] : 0.f;
     }
     __syncthreads();
+    if (SPLIT) {
+        __bf16* dst = reinterpret_cast<__bf16*>(melT) + (size_t)b * (F + 2) * C;
+        for (int i = threadIdx.x; i < C * 64; i += 256) {
+            int tl = i / C, c = i - tl * C, t = t0 + tl;
+            if (t < F) {
+                __bf16 b1, b2, b3;
+                split3(tile[c][tl], b1, b2, b3);
+                __bf16* o = dst + (size_t)(t + 1) * C + c;
+                o[0] = b1; o[plane] = b2; o[2 * plane] = b3;
+            }
+        }
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < 3 * C; i += 256) {
+                const int pl = i / C, c = i - pl * C;
+                dst[pl * plane + c] = (__bf16)0.f;
+                dst[pl * plane + (size_t)(F + 1) * C + c] = (__bf16)0.f;
+            }
+        return;
+    }
     float* dst = melT + (size_t)b * (F + 2) * C;
     for (int i = threadIdx.x; i < C * 64; i += 256) {
         int tl = i / C, c = i - tl * C, t = t0 + tl;
@@ -62,7 +83,13 @@ __global__ __launch_bounds__(256) void mel_transpose_kernel(const float* __restr
 hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels, int frames, hipStream_t s) {
     if (n_mels > 128) return hipErrorInvalidValue;
     dim3 grid((frames + 63) / 64, B);
-    hipLaunchKernelGGL(mel_transpose_kernel, grid, dim3(256), 0, s, mel, melT, n_mels, frames);
+    hipLaunchKernelGGL(mel_transpose_kernel<false>, grid, dim3(256), 0, s, mel, melT, n_mels, frames, (size_t)0);
+    return hipGetLastError();
+}
+hipError_t launch_mel_transpose_split(const float* mel, void* planes, size_t plane_stride, int B, int n_mels, int frames, hipStream_t s) {
+    if (n_mels > 128) return hipErrorInvalidValue;
+    dim3 grid((frames + 63) / 64, B);
+    hipLaunchKernelGGL(mel_transpose_kernel<true>, grid, dim3(256), 0, s, mel, reinterpret_cast<float*>(planes), n_mels, frames, plane_stride);
     return hipGetLastError();
 }
 

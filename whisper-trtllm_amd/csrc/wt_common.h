@@ -174,6 +174,7 @@ struct DeviceGuard {
 
 // launchers (kernels_*.hip)
 hipError_t launch_mel_transpose(const float* mel, float* melT, int B, int n_mels, int frames, hipStream_t s);
+hipError_t launch_mel_transpose_split(const float* mel, void* planes, size_t plane_stride, int B, int n_mels, int frames, hipStream_t s);   // three bf16 planes
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t s);
 hipError_t launch_gemm_f32(const GemmParams& p, hipStream_t s);
 // ---- fp32 GEMM on the bf16 matrix cores.  x = b1 + b2 + b3 with bf16 b1 = rn(x), b2 = rn(x - b1), b3 = rn(x - b1 - b2) represents an fp32
