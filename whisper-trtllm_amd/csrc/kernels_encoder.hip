@@ -1234,9 +1234,12 @@ __global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __res
     gload(0);
     lstore();
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    // One 64-key tile; LAST = the final (possibly ragged) one, peeled: hipcc if-converts the ragged-tile mask into ~90 compare / select /
+    // mask instructions executed on EVERY tile otherwise (as it did in enc_attn_kernel): 532 -> 514 us per launch
+    auto tile = [&](auto LAST_T, const int t) {
+        constexpr bool LAST = decltype(LAST_T)::value;
         const int kv0 = t * XA_BKV;
-        if (t + 1 < ntiles) gload(kv0 + XA_BKV);
+        if (!LAST) gload(kv0 + XA_BKV);
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
@@ -1255,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __res
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1[PA[c]], qf[PB[c]][s], s1, 0, 0, 0);
             }
         }
-        if (kv0 + XA_BKV > S) {
+        if (LAST && kv0 + XA_BKV > S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -1313,11 +1316,13 @@ __global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __res
             }
         }
         __syncthreads();                 // every wave is done with this tile ...
-        if (t + 1 < ntiles) {
+        if (!LAST) {
             lstore();                    // ... the next one goes in (its loads were issued before the products)
             __syncthreads();
         }
-    }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{}, t);
+    tile(std::true_type{}, ntiles - 1);
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
     if (qrow < S) {
         __bf16* op = ctx + ((size_t)b * S + qrow) * d + h * HEAD_DIM + 4 * hh;
