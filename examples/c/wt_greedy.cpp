@@ -3,7 +3,11 @@
 // only include/whisper_trtllm_amd.h and the HIP runtime for device buffers.
 //
 //   hipcc -O2 -Iinclude examples/c/wt_greedy.cpp -Lwhisper-trtllm_amd/lib -lwhisper_trtllm_amd -Wl,-rpath,$PWD/whisper-trtllm_amd/lib -o wt_greedy
-//   ./wt_greedy WhisperEncoder.engine WhisperDecoder.engine mel.f32 <batch> rules.txt [workers]
+//   ./wt_greedy WhisperEncoder.engine WhisperDecoder.engine mel.f32 <batch> rules.txt [workers | stream<slots>]
+//
+// With `stream<slots>` (e.g. stream2) the utterances go through the CONTINUOUS mode of the ABI (wt_decoder_stream_begin / _submit / _run /
+// _collect): `slots` decode rows stay busy, every utterance stops at its own EOS (the reference's run.py:219-226 decodes one clip at a time)
+// and the device refills the slot it frees; the ids come back through pinned host memory.  Each printed row then ends at its EOS.
 //
 // With `workers` > 1 the same batch is decoded by that many host threads at once, each on its own clone of the two engines
 // (wt_engine_clone: one copy of the weights, own workspace / caches / graphs) and its own stream -- distinct handles may be driven
@@ -57,10 +61,54 @@ static int decode_once(wt_engine* enc, wt_engine* dec, const wt_engine_info& ei,
     return 0;
 }
 
+// the same utterances through the continuous mode: `slots` rows decode at a time, submitted in chunks of at most `slots`
+static int decode_stream(wt_engine* enc, wt_engine* dec, const wt_engine_info& ei, const std::vector<char>& mel, int batch, const wt_greedy_params& gp, int slots) {
+    hipStream_t stream;
+    HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    float *d_mel = nullptr, *d_hidden = nullptr;
+    const size_t hid = (size_t)ei.max_source_positions * ei.d_model;
+    HIP(hipMalloc((void**)&d_mel, mel.size()));
+    HIP(hipMalloc((void**)&d_hidden, (size_t)batch * hid * sizeof(float)));
+    HIP(hipMemcpyAsync(d_mel, mel.data(), mel.size(), hipMemcpyHostToDevice, stream));
+    WT(wt_encoder_forward(enc, d_mel, batch, d_hidden, stream));
+    WT(wt_decoder_stream_begin(dec, slots, 0, &gp, stream));
+    std::vector<int32_t> handles((size_t)batch);
+    std::vector<std::vector<int32_t>> rows((size_t)batch);
+    int submitted = 0, collected = 0, n_fin = 0, n_wait = 0, n_steps = 0;
+    while (collected < batch) {
+        while (submitted < batch) {                       // as many chunks as the cache pool takes (WT_E_STATE: collect first)
+            const int n = batch - submitted < slots ? batch - submitted : slots;
+            const int rc = wt_decoder_stream_submit(dec, d_hidden + (size_t)submitted * hid, n, nullptr, handles.data() + submitted, stream);
+            if (rc == WT_E_STATE) break;
+            if (rc != WT_OK) { fprintf(stderr, "wt_decoder_stream_submit -> %d: %s\n", rc, wt_last_error()); return 1; }
+            submitted += n;
+        }
+        WT(wt_decoder_stream_run(dec, submitted < batch ? slots : 0, 0, &n_fin, &n_wait, &n_steps, stream));
+        for (int u = 0; u < submitted; ++u) {             // harvest what has finished (releases its cache row)
+            if (!rows[(size_t)u].empty()) continue;
+            std::vector<int32_t> buf((size_t)gp.max_length);
+            int len = 0;
+            WT(wt_decoder_stream_collect(dec, handles[(size_t)u], buf.data(), gp.max_length, &len));
+            if (len > 0) { buf.resize((size_t)len); rows[(size_t)u] = buf; ++collected; }
+        }
+    }
+    HIP(hipStreamSynchronize(stream));
+    for (int u = 0; u < batch; ++u) {
+        for (size_t t = 0; t < rows[(size_t)u].size(); ++t) printf(t ? " %d" : "%d", rows[(size_t)u][t]);
+        printf("\n");
+    }
+    fprintf(stderr, "continuous mode: %d utterances, %d slots, %d decoder steps\n", batch, slots, n_steps);
+    (void)hipFree(d_mel); (void)hipFree(d_hidden);
+    (void)hipStreamDestroy(stream);
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s <encoder.engine> <decoder.engine> <mel.f32> <batch> <rules.txt> [workers]\n", argv[0]); return 2; }
+    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s <encoder.engine> <decoder.engine> <mel.f32> <batch> <rules.txt> [workers | stream<slots>]\n", argv[0]); return 2; }
     const int batch = atoi(argv[4]);
-    const int workers = argc == 7 ? atoi(argv[6]) : 1;
+    const int stream_slots = (argc == 7 && !strncmp(argv[6], "stream", 6)) ? atoi(argv[6] + 6) : 0;
+    const int workers = (argc == 7 && !stream_slots) ? atoi(argv[6]) : 1;
+    if (argc == 7 && !strncmp(argv[6], "stream", 6) && (stream_slots < 1 || stream_slots > 16)) { fprintf(stderr, "stream<slots>: 1..16 slots\n"); return 2; }
     if (workers < 1 || workers > 16) { fprintf(stderr, "workers must be 1..16\n"); return 2; }
     std::vector<char> enc_blob = read_file(argv[1]), dec_blob = read_file(argv[2]), mel = read_file(argv[3]);
 
@@ -90,6 +138,12 @@ int main(int argc, char** argv) {
     const size_t mel_floats = (size_t)batch * ei.n_mels * 2 * ei.max_source_positions;
     if (mel.size() != mel_floats * sizeof(float)) { fprintf(stderr, "mel file holds %zu bytes, expected %zu\n", mel.size(), mel_floats * sizeof(float)); return 2; }
 
+    if (stream_slots) {
+        const int rc = decode_stream(encs[0], decs[0], ei, mel, batch, gp, stream_slots);
+        wt_engine_close(encs[0]);
+        wt_engine_close(decs[0]);
+        return rc;
+    }
     std::vector<std::vector<int32_t>> ids((size_t)workers);
     std::vector<int> lens((size_t)workers, 0), rcs((size_t)workers, 0);
     std::vector<std::thread> threads;

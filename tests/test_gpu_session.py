@@ -316,6 +316,14 @@ def test_plain_c_host_of_the_c_abi(wt, tmp_path):
                            str(tmp_path / "rules.txt"), "4"], capture_output=True, text=True, timeout=300)
     assert out4.returncode == 0, out4.stderr[-2000:]
     assert out4.stdout == out.stdout
+    # ... and through the continuous mode of the C-ABI (wt_decoder_stream_*, 2 slots for 3 utterances): every row ends at its own EOS
+    outs = subprocess.run([exe, str(tmp_path / "enc.engine"), str(tmp_path / "dec.engine"), str(tmp_path / "mel.f32"), str(mel.shape[0]),
+                           str(tmp_path / "rules.txt"), "stream2"], capture_output=True, text=True, timeout=300)
+    assert outs.returncode == 0, outs.stderr[-2000:]
+    rows = [[int(t) for t in line.split()] for line in outs.stdout.strip().splitlines()]
+    eos = cfg["eos_token_id"]
+    expect = [[int(t) for t in (list(r)[:list(r).index(eos, 1) + 1] if eos in list(r)[1:] else r)] for r in want]
+    assert rows == expect
 
 
 def _write_engine_dir(wt, tmp_path, cfg, weights):
