@@ -193,8 +193,9 @@ def bench_gemm_x3(M=12000):
     """launch_gemm_x3 (fp32 product from six bf16 MFMAs of exactly split operands) beside the native fp32 MFMA kernel on the encoder's
     shapes; TFLOP/s of USEFUL fp32 work (2 M N K); the split kernel issues 6x that in bf16 MFMA flops."""
     for (N, K, act) in ((3072, 1024, 0), (1024, 1024, 0), (4096, 1024, 1), (1024, 4096, 0), (2048, 1024, 0)):
-        A = torch.randn(M, K, device="cuda")
-        W = torch.randn(4, N, K, device="cuda") * 0.03
+        zero = 0.0 if os.environ.get("MB_ZERO") else 1.0     # all-zero operands: the clock the chip holds when the MFMAs toggle nothing
+        A = torch.randn(M, K, device="cuda") * zero
+        W = torch.randn(4, N, K, device="cuda") * 0.03 * zero
         bias = torch.zeros(N, device="cuda")
         C = torch.empty(M, N, device="cuda")
         a_pl = torch.empty(3 * M * K, dtype=torch.bfloat16, device="cuda")
