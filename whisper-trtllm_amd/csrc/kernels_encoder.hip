@@ -1160,12 +1160,15 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
 //   O^T[dv][query] += V^T . P^T (B = P straight from the S^T accumulator registers: registers 8t .. 8t+7 are k-step t, whose key order
 //                                16t + 8 (j >> 2) + 4 h + (j & 3) is matched by reading V^T with the same permutation from a TRANSPOSED V
 //                                tile in LDS -- the scheme of enc_attn_f16_kernel).
-// LDS: one 64-key stage of 3 x (K [64][72] + V^T [64][68]) bf16 = 53,760 B (K rows padded to 144 B: conflict-free ds_read_b128; V^T rows
-// to 136 B: conflict-free ds_read_b64), single-buffered so that two workgroups share a CU: the next tile's global loads are issued before
-// the current tile's products and stored behind a second barrier.
-constexpr int XA_BQ = 128, XA_BKV = 64, XA_KLD = 72, XA_VLD = 68;                   // strides in bf16 elements
-constexpr int XA_PLANE = XA_BKV * XA_KLD + HEAD_DIM * XA_VLD;                        // one plane's (K, V^T) tile
-constexpr int XA_SMEM = 3 * XA_PLANE * 2;                                            // 53,760 B
+// LDS: one 64-key stage of 3 x (K [64][72] + V [64][96]) bf16 = 64,512 B.  K rows are padded to 144 B (conflict-free ds_read_b128).  V stays
+// ROW-major as it comes from memory (two 16-byte stores per thread and plane) and the V^T fragments are read with ds_read_b64_tr_b16: each
+// 16-lane group takes a block of 4 keys x 16 head dims and every lane receives the four keys of its own head dim.  Rows of 192 B put the four
+// key rows of a block on the four 16-bank quarters (48 q mod 64 = 0, 48, 32, 16): conflict-free.  (Until late round 4 the tile was stored
+// transposed with 48 two-byte stores per thread and tile, two- to four-way conflicting.)  Single-buffered so that two workgroups share a CU:
+// the next tile's global loads are issued before the current tile's products and stored behind a second barrier.
+constexpr int XA_BQ = 128, XA_BKV = 64, XA_KLD = 72, XA_VLD = 96;                   // strides in bf16 elements
+constexpr int XA_PLANE = XA_BKV * XA_KLD + XA_BKV * XA_VLD;                          // one plane's (K, V) tile
+constexpr int XA_SMEM = 3 * XA_PLANE * 2;                                            // 64,512 B
 __global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ ctx, int S, int H,
                                                              size_t in_plane, size_t out_plane) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xa_raw[];
@@ -1214,17 +1217,20 @@ __global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __res
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             __bf16* Ks_ = smem + pl * XA_PLANE;
-            __bf16* Vt_ = Ks_ + XA_BKV * XA_KLD;
+            __bf16* Vs_ = Ks_ + XA_BKV * XA_KLD;
             *reinterpret_cast<bf16x8*>(Ks_ + r0 * XA_KLD + c8 * 8) = rk[pl][0];
             *reinterpret_cast<bf16x8*>(Ks_ + (r0 + 32) * XA_KLD + c8 * 8) = rk[pl][1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                Vt_[(c8 * 8 + e) * XA_VLD + r0] = rv[pl][0][e];
-                Vt_[(c8 * 8 + e) * XA_VLD + r0 + 32] = rv[pl][1][e];
-            }
+            *reinterpret_cast<bf16x8*>(Vs_ + r0 * XA_VLD + c8 * 8) = rv[pl][0];
+            *reinterpret_cast<bf16x8*>(Vs_ + (r0 + 32) * XA_VLD + c8 * 8) = rv[pl][1];
         }
     };
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // the six partial products, the small ones first
+    // transposed V reads: lane 32 hh + 16 g + 4 q + p supplies row (4 hh + q), head dims 16 g + 4 p .. + 3 of a block and receives the
+    // four keys 4 hh .. 4 hh + 3 of head dim 16 g + 4 q + p = l31 (cdna guide T10)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* tr_ptr_t;
+    const int v_tr = (4 * hh + ((lane >> 2) & 3)) * XA_VLD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto tr4 = [&](const __bf16* ptr) { return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)ptr)); };
 
     f32x16 o0, o1;
 #pragma unroll
@@ -1302,9 +1308,9 @@ __global__ __launch_bounds__(256, 2) void enc_attn_x3_kernel(const __bf16* __res
                 bf16x8 va0[3], va1[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const __bf16* vp = smem + pl * XA_PLANE + XA_BKV * XA_KLD + l31 * XA_VLD + 4 * hh + kb;
-                    const bf16x4 a00 = *reinterpret_cast<const bf16x4*>(vp), a01 = *reinterpret_cast<const bf16x4*>(vp + 8);
-                    const bf16x4 a10 = *reinterpret_cast<const bf16x4*>(vp + 32 * XA_VLD), a11 = *reinterpret_cast<const bf16x4*>(vp + 32 * XA_VLD + 8);
+                    const __bf16* vp = smem + pl * XA_PLANE + XA_BKV * XA_KLD + kb * XA_VLD + v_tr;
+                    const bf16x4 a00 = tr4(vp), a01 = tr4(vp + 8 * XA_VLD);
+                    const bf16x4 a10 = tr4(vp + 32), a11 = tr4(vp + 8 * XA_VLD + 32);
                     va0[pl] = bf16x8{a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
                     va1[pl] = bf16x8{a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
                 }
