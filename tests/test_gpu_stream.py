@@ -7,12 +7,14 @@ What must hold, whatever slot an utterance lands in, whenever it is admitted and
   * they equal the engine's own batch-1 decode of it (row independence of every kernel of the step);
   * every utterance comes back exactly once, in the order asked for; runs are bitwise reproducible."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -217,3 +219,15 @@ def test_run_py_continuous_batching_and_pipeline_workers(wt, tmp_path):
         assert rows[1][i][-1] == eos and len(rows[1][i]) <= fe[i] + 2        # its forced EOS, or the model's own before it
         np.testing.assert_array_equal(rows[1][i], rows[2][i])
         np.testing.assert_array_equal(rows[1][i], rows[3][i])
+
+
+def test_stream_churn_thousands_of_utterances_through_one_open_stream():
+    """tools/soak_stream.py at a tenth of its default size: 5000 utterances with random forced lengths through one open stream of 8 slots
+    (slots refilled ~5000 times, submissions in chunks of <= 16 while steps are in flight), every id row equal to the batch decode.
+    The full run (50,000 utterances: the mailbox's 16-bit step counter and 15-bit admission counter both wrap) is
+    profiles/r04d_soak_stream.txt."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_stream.py"), "5000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "stream soak ok: 5000 utterances" in out.stdout
