@@ -418,6 +418,20 @@ def main():
                                        "enc_attn_total_ms": round(ms_eattn, 3),
                                        "enc_attn_kernel": "enc_attn_kernel (v_mfma_f32_32x32x2_f32)" if (os.environ.get("WT_TUNING") == "1" and os.environ.get("WT_ATTN_X3") == "0")
                                                           else "enc_attn_x3_kernel (both products as 6 bf16 MFMAs of exactly split operands, fp32 scores / softmax / accumulators); enc_attn_tflops = useful fp32 flops"}
+            # what the bf16 matrix pipe of THIS device sustains on random operands with no memory traffic (a bare MFMA loop run as a child
+            # process for ~2 s: tools/probes/mfma_power --quick): the x3 kernels run against the chip's power management, so the data-sheet
+            # peak is not reachable on real data by any schedule
+            probe = os.path.join(ROOT, "tools", "probes", "mfma_power", "mfma_power")
+            if os.path.exists(probe) and not under_rocprof():
+                try:
+                    import subprocess
+                    torch.cuda.synchronize()
+                    line = subprocess.run([probe, "--quick"], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[-1]
+                    sustained = json.loads(line)
+                    out["roofline_encoder"]["bare_mfma_loop_random_operands"] = sustained
+                    out["roofline_encoder"]["frac_of_bare_mfma_loop"] = round(6 * gemm_tf / sustained["tflops"], 4)
+                except Exception as exc:   # the probe is context, never a reason to lose the bench line
+                    log(f"mfma_power probe failed: {exc!r}")
         else:
             out["roofline_encoder"] = {"bound": "mfma", "kernel": "gemm_f16_dma4_kernel / gemm_f16_dma3_kernel / gemm_f16_dma_kernel (v_mfma_f32_16x16x32_f16)" if half else "gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32)",
                                        "achieved": round(gemm_tf, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(gemm_tf / enc_peak, 4),

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(512, 1) void mfma_loop(const bf16x8* __restrict__ s
 
 static unsigned short bf16_of(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && std::string(argv[1]) == "--quick";   // bench.py: random operands, 32x32x16, two waves per SIMD only; one JSON line
     const int n_src = 65536 * 8;
     std::vector<unsigned short> h(n_src);
     srand(1);
@@ -65,11 +67,12 @@ int main() {
     hipMalloc(&src, n_src * 2); hipMalloc(&sink, 256 * 512 * 4); hipMalloc(&stamps, 256 * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 100000;
-    for (int zero = 0; zero < 2; ++zero) {
+    for (int zero = 0; zero < (quick ? 1 : 2); ++zero) {
         for (auto& v : h) v = zero ? 0 : bf16_of((float)rand() / RAND_MAX * 2.f - 1.f);
         hipMemcpy(src, h.data(), n_src * 2, hipMemcpyHostToDevice);
-        for (int big = 1; big >= 0; --big)
+        for (int big = 1; big >= (quick ? 1 : 0); --big)
             for (int threads : {256, 512}) {
+                if (quick && threads != 512) continue;
                 auto launch = [&]() {
                     if (big) hipLaunchKernelGGL(mfma_loop<true>, dim3(256), dim3(threads), 0, 0, (const bf16x8*)src, (float*)sink, (unsigned long long*)stamps, iters);
                     else hipLaunchKernelGGL(mfma_loop<false>, dim3(256), dim3(threads), 0, 0, (const bf16x8*)src, (float*)sink, (unsigned long long*)stamps, iters);
@@ -87,6 +90,11 @@ int main() {
                 for (int i = 0; i < 256; ++i) ghz.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 0.1);
                 std::sort(ghz.begin(), ghz.end());
                 const double flops = 256.0 * (threads / 64) * (double)iters * 8 * 32768.0 * reps;      // 2 * 32 * 32 * 16 per big MFMA
+                if (quick) {
+                    printf("{\"mfma\": \"v_mfma_f32_32x32x16_bf16\", \"operands\": \"random, in registers\", \"waves_per_simd\": 2, \"tflops\": %.1f, \"clock_ghz\": %.2f}\n",
+                           flops / (ms * 1e-3) * 1e-12, ghz[128]);
+                    continue;
+                }
                 printf("%s operands, %s, %d wave(s)/SIMD: %8.1f TFLOP/s  in-kernel clock %.2f GHz (median), %6.1f cycles per 32x32x16-equivalent per SIMD\n",
                        zero ? "zero  " : "random", big ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", threads / 256,
                        flops / (ms * 1e-3) * 1e-12, ghz[128], (ms * 1e-3 / reps) * ghz[128] * 1e9 / ((double)iters * 8 * (threads / 256)));

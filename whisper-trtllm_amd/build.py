@@ -75,6 +75,22 @@ def build_c_example(verbose: bool = False) -> str:
     return exe
 
 
+def build_mfma_probe(verbose: bool = False) -> str:
+    """tools/probes/mfma_power/mfma_power: a bare bf16 MFMA loop (operands in registers, no memory traffic).  `bench.py` runs it with
+    --quick for the rate the matrix pipe of THIS device sustains on random operands under its power management -- the practical ceiling
+    the x3 GEMM's TFLOP/s are shown beside."""
+    d = os.path.join(os.path.dirname(HERE), "tools", "probes", "mfma_power")
+    src, exe = os.path.join(d, "mfma_power.hip"), os.path.join(d, "mfma_power")
+    if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+        return exe
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-w", "-o", exe, src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
     print(build_c_example(verbose=True))
+    print(build_mfma_probe(verbose=True))
