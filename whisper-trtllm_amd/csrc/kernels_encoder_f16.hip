@@ -6,6 +6,7 @@
 
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace wt {
 
@@ -1226,14 +1227,17 @@ hipError_t launch_gemm_f16(const GemmParams& p, bool out_half, hipStream_t s, in
 //   S^T[key][query] = K . Q^T  -> the query sits on the lane, softmax statistics are lane-local;
 //   O^T[dv][query] += V^T . P^T -> P goes from the S^T accumulator registers straight into the next MFMA's B operand
 //                                  (registers 8t..8t+7 = k-step t; their key order 16t + 8(j>>2) + 4h + (j&3) is matched
-//                                  by reading V^T with the same permutation from a TRANSPOSED V tile in LDS).
+//                                  by the V^T fragments' key order).
 // qkv fp16 [B*S][3d] -> ctx fp16 [B*S][d].  128 queries per block (4 waves x 32), 64-key tiles, double-buffered LDS:
-// K rows padded to 144 B (conflict-free ds_read_b128), V^T rows to 136 B (conflict-free ds_read_b64).
+// K rows padded to 144 B (conflict-free ds_read_b128); V stays ROW-major as it comes from memory (192-byte rows) and the V^T fragments are
+// read with ds_read_b64_tr_b16: a 16-lane group takes 4 keys x 16 head dims, a lane receives the four keys of its own head dim; the four
+// key rows of a block sit on the four 16-bank quarters (48 q mod 64): conflict-free.  Until late round 4 the tile was stored transposed
+// with 16 two-byte stores per thread and tile: SQ_LDS_BANK_CONFLICT = 39 % of the LDS-active cycles (profiles/r04d_enc_attn_pmc_counters.txt).
 typedef float f32x16h __attribute__((ext_vector_type(16)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-constexpr int HA_BQ = 128, HA_BKV = 64, HA_KLD = 72, HA_VLD = 68;           // strides in halfs
-constexpr int HA_TILE = HA_BKV * HA_KLD + HEAD_DIM * HA_VLD;                 // halfs per (K, V^T) stage
-constexpr int HA_SMEM = 2 * HA_TILE * 2;                                     // 35,840 B
+constexpr int HA_BQ = 128, HA_BKV = 64, HA_KLD = 72, HA_VLD = 96;           // strides in halfs
+constexpr int HA_TILE = HA_BKV * HA_KLD + HA_BKV * HA_VLD;                   // halfs per (K, V) stage
+constexpr int HA_SMEM = 2 * HA_TILE * 2;                                     // 43,008 B
 
 __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __restrict__ qkv, __half* __restrict__ ctx, int S, int H) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ha_raw[];
@@ -1274,14 +1278,18 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
 #define HA_LSTORE(buf_)                                                                        \
     do {                                                                                       \
         _Float16* Ks_ = smem + (buf_) * HA_TILE;                                               \
-        _Float16* Vt_ = Ks_ + HA_BKV * HA_KLD;                                                 \
+        _Float16* Vs_ = Ks_ + HA_BKV * HA_KLD;                                                 \
         *reinterpret_cast<h8*>(Ks_ + r0 * HA_KLD + c8 * 8) = rk0;                              \
         *reinterpret_cast<h8*>(Ks_ + (r0 + 32) * HA_KLD + c8 * 8) = rk1;                       \
-        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                     \
-            Vt_[(c8 * 8 + e_) * HA_VLD + r0] = rv0[e_];                                        \
-            Vt_[(c8 * 8 + e_) * HA_VLD + r0 + 32] = rv1[e_];                                   \
-        }                                                                                      \
+        *reinterpret_cast<h8*>(Vs_ + r0 * HA_VLD + c8 * 8) = rv0;                              \
+        *reinterpret_cast<h8*>(Vs_ + (r0 + 32) * HA_VLD + c8 * 8) = rv1;                       \
     } while (0)
+    // transposed V reads: lane 32 hh + 16 g + 4 q + p supplies row (4 hh + q), head dims 16 g + 4 p .. + 3 of a block and receives the four
+    // keys 4 hh .. 4 hh + 3 of head dim 16 g + 4 q + p = l31 (cdna guide T10)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* tr_ptr_t;
+    const int v_tr = (4 * hh + ((lane >> 2) & 3)) * HA_VLD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto tr4 = [&](const _Float16* ptr) { return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)ptr)); };
 
     f32x16h o0, o1;
 #pragma unroll
@@ -1291,11 +1299,14 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
     HA_GLOAD(0);
     HA_LSTORE(0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    // One 64-key tile; LAST = the final (possibly ragged) one, peeled: hipcc if-converts the ragged-tile mask into compares and selects
+    // executed on EVERY tile otherwise (as it did in the fp32 kernels)
+    auto tile = [&](auto LAST_T, const int t) {
+        constexpr bool LAST = decltype(LAST_T)::value;
         const int cur = t & 1, kv0 = t * HA_BKV;
-        if (t + 1 < ntiles) HA_GLOAD(kv0 + HA_BKV);
+        if (!LAST) HA_GLOAD(kv0 + HA_BKV);
         const _Float16* Ks = smem + cur * HA_TILE;
-        const _Float16* Vt = Ks + HA_BKV * HA_KLD;
+        const _Float16* Vs = Ks + HA_BKV * HA_KLD;
 
         f32x16h s0, s1;
 #pragma unroll
@@ -1308,7 +1319,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
         }
-        if (kv0 + HA_BKV > S) {
+        if (LAST && kv0 + HA_BKV > S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -1337,7 +1348,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
             o1[r] *= alpha;
         }
         // P.V: k-step (kt, t2) covers keys kt*32 + 16*t2 .. +15; B fragment = accumulator registers 8*t2 .. 8*t2+7
-        const _Float16* vp = Vt + l31 * HA_VLD + 4 * hh;
+        const _Float16* vp = Vs + v_tr;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -1346,17 +1357,19 @@ __global__ __launch_bounds__(256, 2) void enc_attn_f16_kernel(const __half* __re
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (_Float16)(kt == 0 ? s0[8 * t2 + j] : s1[8 * t2 + j]);
                 const int kb = kt * 32 + 16 * t2;
-                const h4 a00 = *reinterpret_cast<const h4*>(vp + kb), a01 = *reinterpret_cast<const h4*>(vp + kb + 8);
-                const h4 a10 = *reinterpret_cast<const h4*>(vp + 32 * HA_VLD + kb), a11 = *reinterpret_cast<const h4*>(vp + 32 * HA_VLD + kb + 8);
+                const h4 a00 = tr4(vp + kb * HA_VLD), a01 = tr4(vp + (kb + 8) * HA_VLD);
+                const h4 a10 = tr4(vp + kb * HA_VLD + 32), a11 = tr4(vp + (kb + 8) * HA_VLD + 32);
                 const h8 va0 = {a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
                 const h8 va1 = {a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va0, pf, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(va1, pf, o1, 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) HA_LSTORE(cur ^ 1);
+        if (!LAST) HA_LSTORE(cur ^ 1);
         __syncthreads();
-    }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{}, t);
+    tile(std::true_type{}, ntiles - 1);
 #undef HA_GLOAD
 #undef HA_LSTORE
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
